@@ -1,0 +1,57 @@
+"""Builds convnet_amd/lib/libconvnet_hip.so (the C-ABI library declared in include/convnet_hip.h)
+from convnet_amd/csrc/*.hip with hipcc for gfx950.  hipcc cross-compiles without a GPU; the .so
+stays in-tree (git-ignored) so it travels to the GPU box with the snapshot."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "lib", "libconvnet_hip.so")
+SOURCES = ["state.hip", "gather_gemm.hip", "pool_norm.hip", "elementwise.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
+    objdir = os.path.join(HERE, "lib", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(SRC, "common.h"), os.path.join(HERE, "..", "include", "convnet_hip.h")]
+    objs, procs = [], []
+    for s in SOURCES:
+        src = os.path.join(SRC, s)
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            cmd = ["hipcc", *FLAGS, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            print(f"--- {s} failed ---\n{out}", file=sys.stderr)
+        elif verbose and out.strip():
+            print(out)
+    if failed:
+        raise RuntimeError("hipcc failed")
+    if force or procs or _stale(OUT, objs):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stdout, r.stderr, file=sys.stderr)
+            raise RuntimeError("link failed")
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,51 @@
+// Internal helpers shared by the HIP translation units of libconvnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/convnet_hip.h"
+
+namespace chip {
+
+// One current stream for the whole library (the reference ran everything on stream 0 of the
+// current device, cudamat.cu; it is equally non-thread-safe).
+hipStream_t stream();
+// Grow-only scratch arena.  Returns a device pointer valid until the next call that asks for more
+// than the current capacity (growth synchronises the stream first, so in-flight users stay valid).
+void* workspace(size_t bytes);
+void set_last_error(const char* msg);
+void note_kernel(const char* name, double flops, int blocks, int split_k);
+
+[[noreturn]] inline void fatal(const char* what, const char* file, int line) {
+  // Same policy as the reference's conv back-end: shape/HIP errors are unrecoverable
+  // (cudamat_conv_gemm.cu:35-42 getLastCudaError -> exit(EXIT_FAILURE)).
+  fprintf(stderr, "libconvnet_hip: fatal: %s (%s:%d)\n", what, file, line);
+  exit(EXIT_FAILURE);
+}
+
+#define CHIP_CHECK(expr)                                                            \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) ::chip::fatal(hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+#define CHIP_REQUIRE(cond)                                       \
+  do {                                                           \
+    if (!(cond)) ::chip::fatal("check failed: " #cond, __FILE__, __LINE__); \
+  } while (0)
+
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_last_error(hipGetErrorString(e));
+    return CUDA_ERROR;
+  }
+  return 0;
+}
+
+inline int divup(int a, int b) { return (a + b - 1) / b; }
+inline size_t numel(const cudamat* m) { return (size_t)m->size[0] * (size_t)m->size[1]; }
+
+}  // namespace chip

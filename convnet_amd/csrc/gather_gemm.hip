@@ -1,0 +1,867 @@
+// fp32-MFMA implicit-GEMM kernels for the conv_edge / fc_edge hot path on gfx950.
+//
+// Everything the reference lowers to im2col + cublasSgemm + scatter (cudamat_conv_gemm.cu:545-960:
+// _convUpGemm / _convDownGemm / _convOutpGemm) and cublasSgemm for FC (cudamat.cu:2130-2152) is
+// expressed here as two kernel families operating directly on the reference's CHWN layout
+// (image index fastest), with no im2col buffer and no atomics:
+//
+//   gg_kernel   "gather-GEMM":  out[row r, (pixel m, image n)] = sum_k A[r,k] * src[n, tap(m,k)]
+//               - fprop  (r = filter,        k = (c,ky,kx), A = W            )   convUpGemm
+//               - dgrad  (r = input channel, k = (f,a,b),   A = per-stride-class re-laid W)  convDownGemm
+//               - FC fwd / FC dgrad as the 1-pixel case (dot NT / NN)
+//   wg_kernel   "outer-GEMM":   dW[k=(c,ky,kx), f] = sum_{m,n} patch(src)[n,k,m] * dout[n,f,m]
+//               - conv wgrad (convOutpGemm) and FC wgrad (dot TN), split over (m,n) with a
+//                 deterministic second-stage reduce (what the reference's partial_sum was for,
+//                 src/conv_edge.cc:191-205).
+//
+// MFMA mapping (v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2]*B[2x32], lane l holds A[l&31][l>>5],
+// B[l>>5][l&31]; D col = l&31, row = (reg&3)+8*(reg>>2)+4*(l>>5)).  The image index n is the
+// contiguous dimension of every activation, so it is mapped to the D *column* (lane) dimension:
+// loads of 4 consecutive images per lane are one ds_read_b128 / global dwordx4 and stores are
+// 512 contiguous bytes per half-wave.  64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak (fp32 matrix).
+#include "common.h"
+
+namespace chip {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int BK = 16;  // reduction depth per LDS stage (gg_kernel)
+
+struct GGParams {
+  const float* A;
+  const float* src;
+  float* dst;
+  const float* bias;  // per output row, nullable
+  float* partial;     // split-K slabs, nullable
+  int R, K, N;
+  int lda;            // A[r + lda*k] (r-contiguous) or A[k + lda*r] (k-contiguous)
+  int GX, G;          // output pixel grid of this launch: G = GY*GX pixels, m = oy*GX + ox
+  int TX, TYX;        // taps: k = ch*TYX + a*TX + b
+  int SH, SW;         // source image
+  int ssy, ssx, y0, x0, dir;       // source row of tap a: oy*ssy + y0 + dir*a
+  int DW, DP;         // dest image width, pixels per channel (DH*DW)
+  int dsy, dsx, dy0, dx0;          // dest pixel: (oy*dsy + dy0, ox*dsx + dx0)
+  int nblk;           // ceil(N/128) wave-columns per pixel
+  int ncols;          // G*nblk wave-columns in total
+  int row_tiles, col_tiles;
+  int chunks_per_split;  // in BK units
+  int splits;
+  size_t slab;        // floats per split slab (= dst extent)
+  float scaleTargets;
+  int relu;
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// XCD-aware block -> tile map: hardware places block b on XCD b%8 (observed; speed only).  Give
+// each XCD a contiguous run of logical tiles, ordered row-tile-fastest, so blocks that share a
+// source-column tile run on one XCD's L2 back to back.
+__device__ __forceinline__ int xcd_remap(int b, int total) {
+  const int per = (total + 7) >> 3;
+  return (b & 7) * per + (b >> 3);
+}
+
+template <int WR, int WC, int MT, bool A_KCONTIG, bool VEC>
+__global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg_kernel(const GGParams p) {
+  constexpr int NT = WR * WC * 64;
+  constexpr int ROWS = WR * MT * 32;
+  constexpr int APITCH = A_KCONTIG ? (BK + 4) : ROWS;
+  constexpr int A_STAGE = A_KCONTIG ? ROWS * APITCH : BK * ROWS;
+  constexpr int B_STAGE = WC * BK * 128;
+  constexpr int NA = ((A_KCONTIG ? ROWS * (BK / 4) : BK * (ROWS / 4)) + NT - 1) / NT;
+  constexpr int NB = (WC * BK * 32 + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][A_STAGE]
+  float* Bs = smem + 2 * A_STAGE;   // [2][B_STAGE]
+
+  const int tiles = p.row_tiles * p.col_tiles;
+  const int per = (tiles + 7) >> 3;
+  const int L = xcd_remap(blockIdx.x, tiles);
+  if (L >= tiles || (int)blockIdx.x >= per * 8) return;
+  const int row_tile = L % p.row_tiles, col_tile = L / p.row_tiles;
+  const int split = blockIdx.y;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave / WC, wc = wave % WC;
+  const int li = lane & 31, lh = lane >> 5;
+  const int r0 = row_tile * ROWS;
+  const int N = p.N;
+
+  // ---- per-thread constants for the B (source) staging slots -----------------------------------
+  int b_ys0[NB], b_xs0[NB], b_n[NB], b_lds[NB], b_krow[NB];
+  bool b_ok[NB];
+#pragma unroll
+  for (int it = 0; it < NB; ++it) {
+    const int idx = tid + it * NT;
+    const int wcol = idx / (BK * 32), krow = (idx / 32) % BK, c4 = idx % 32;
+    const int colid = col_tile * WC + wcol;
+    const bool ok = idx < WC * BK * 32 && colid < p.ncols;
+    const int m = ok ? colid / p.nblk : 0, blk = ok ? colid % p.nblk : 0;
+    const int oy = m / p.GX, ox = m - oy * p.GX;
+    b_ys0[it] = oy * p.ssy + p.y0;
+    b_xs0[it] = ox * p.ssx + p.x0;
+    b_n[it] = blk * 128 + 4 * c4;
+    b_ok[it] = ok;
+    b_krow[it] = krow;
+    b_lds[it] = (wcol * BK + krow) * 128 + 4 * c4;
+  }
+
+  const int kbeg = split * p.chunks_per_split * BK;
+  int kend = kbeg + p.chunks_per_split * BK;
+  if (kend > p.K) kend = p.K;
+  const int nchunks = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+
+  f32x4 ra[NA], rb[NB];
+
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int idx = tid + it * NT;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (!A_KCONTIG) {
+        const int krow = idx / (ROWS / 4), c4 = idx % (ROWS / 4);
+        const int k = k0 + krow, r = r0 + 4 * c4;
+        if (idx < BK * (ROWS / 4) && k < kend) {
+          const float* ap = p.A + (size_t)p.lda * k + r;
+          if (VEC) {
+            if (r < p.R) v = ld4(ap);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (r + e < p.R) v[e] = ap[e];
+          }
+        }
+      } else {
+        const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+        const int k = k0 + 4 * c4, r = r0 + row;
+        if (idx < ROWS * (BK / 4) && r < p.R) {
+          const float* ap = p.A + (size_t)p.lda * r + k;
+          if (VEC) {
+            if (k < kend) v = ld4(ap);  // VEC implies K%4==0 and split boundaries %4==0
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (k + e < kend) v[e] = ap[e];
+          }
+        }
+      }
+      ra[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int k = k0 + b_krow[it];
+      if (b_ok[it] && k < kend) {
+        const int ch = k / p.TYX;
+        const int tap = k - ch * p.TYX;
+        const int a = tap / p.TX, b = tap - a * p.TX;
+        const int ys = b_ys0[it] + p.dir * a, xs = b_xs0[it] + p.dir * b;
+        if (ys >= 0 && ys < p.SH && xs >= 0 && xs < p.SW) {
+          const float* sp = p.src + ((size_t)(ch * p.SH + ys) * p.SW + xs) * N + b_n[it];
+          if (VEC) {
+            if (b_n[it] < N) v = ld4(sp);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (b_n[it] + e < N) v[e] = sp[e];
+          }
+        }
+      }
+      rb[it] = v;
+    }
+  };
+
+  auto stash = [&](int buf) {
+    float* as = As + buf * A_STAGE;
+    float* bs = Bs + buf * B_STAGE;
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int idx = tid + it * NT;
+      if (!A_KCONTIG) {
+        if (idx < BK * (ROWS / 4)) st4(as + 4 * idx, ra[it]);
+      } else {
+        const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+        if (idx < ROWS * (BK / 4)) st4(as + row * APITCH + 4 * c4, ra[it]);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int idx = tid + it * NT;
+      if (idx < WC * BK * 32) st4(bs + b_lds[it], rb[it]);
+    }
+  };
+
+  f32x16 acc[MT][4];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+
+  if (nchunks > 0) {
+    fetch(kbeg);
+    stash(0);
+  }
+  __syncthreads();
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) fetch(kbeg + (c + 1) * BK);
+    const float* as = As + buf * A_STAGE;
+    const float* bs = Bs + buf * B_STAGE + wc * BK * 128 + 4 * li;
+    if (!A_KCONTIG) {
+      const float* ar = as + wr * MT * 32 + li;
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const int krow = 2 * kk + lh;
+        float a[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a[t] = ar[krow * ROWS + t * 32];
+        const f32x4 b4 = ld4(bs + krow * 128);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b4[u], acc[t][u], 0, 0, 0);
+      }
+    } else {
+      const float* ar = as + (wr * MT * 32 + li) * APITCH + 4 * lh;
+#pragma unroll
+      for (int q = 0; q < BK / 8; ++q) {
+        f32x4 a4[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a4[t] = ld4(ar + t * 32 * APITCH + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const f32x4 b4 = ld4(bs + (8 * q + 4 * lh + e) * 128);
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t][e], b4[u], acc[t][u], 0, 0, 0);
+        }
+      }
+    }
+    if (c + 1 < nchunks) stash(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  const int colid = col_tile * WC + wc;
+  if (colid >= p.ncols) return;
+  const int m = colid / p.nblk, blk = colid - m * p.nblk;
+  const int oy = m / p.GX, ox = m - oy * p.GX;
+  const int dpix = (oy * p.dsy + p.dy0) * p.DW + ox * p.dsx + p.dx0;
+  const int n = blk * 128 + 4 * li;
+  if (n >= N) return;
+  float* base = (p.splits > 1 ? p.partial + (size_t)split * p.slab : p.dst) + (size_t)dpix * N + n;
+  const bool fin = p.splits == 1;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = r0 + wr * MT * 32 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+      if (row >= p.R) continue;
+      f32x4 v = {acc[t][0][reg], acc[t][1][reg], acc[t][2][reg], acc[t][3][reg]};
+      float* dp = base + (size_t)row * p.DP * N;
+      if (fin) {
+        const float bv = p.bias ? p.bias[row] : 0.f;
+        if (VEC) {
+          if (p.scaleTargets != 0.f) {
+            const f32x4 o = ld4(dp);
+            v = p.scaleTargets * o + v;
+          }
+          v = v + bv;
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          st4(dp, v);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e < N) {
+              float x = v[e];
+              if (p.scaleTargets != 0.f) x = p.scaleTargets * dp[e] + x;
+              x += bv;
+              if (p.relu) x = x > 0.f ? x : 0.f;
+              dp[e] = x;
+            }
+          }
+        }
+      } else {
+        if (VEC) {
+          st4(dp, v);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < N) dp[e] = v[e];
+        }
+      }
+    }
+  }
+}
+
+// dst = scaleTargets*dst + sum_s slab[s]  (+bias[row], relu) over a full dst extent.
+__global__ void gg_reduce_kernel(float* __restrict__ dst, const float* __restrict__ partial, const float* __restrict__ bias,
+                                 size_t total, size_t slab, int splits, size_t per_row, float scaleTargets, int relu) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += partial[(size_t)k * slab + i];
+    if (scaleTargets != 0.f) s = scaleTargets * dst[i] + s;
+    if (bias) s += bias[i / per_row];
+    if (relu) s = s > 0.f ? s : 0.f;
+    dst[i] = s;
+  }
+}
+
+// Re-lay the filter bank for one stride class of the input-gradient gather:
+// Wt[c + C*(b + TXc*(a + TYc*f))] = W[f + F*((cx + s_x*b) + Kx*((cy + s_y*a) + Ky*c))].
+__global__ void dgrad_filter_kernel(const float* __restrict__ W, float* __restrict__ Wt, int F, int C, int Ky, int Kx, int cy,
+                                    int cx, int sy, int sx, int TYc, int TXc) {
+  const size_t total = (size_t)C * TXc * TYc * F;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    size_t r = i / C;
+    const int b = r % TXc;
+    r /= TXc;
+    const int a = r % TYc;
+    const int f = r / TYc;
+    Wt[i] = W[(size_t)f + (size_t)F * ((cx + sx * b) + Kx * ((cy + sy * a) + Ky * c))];
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// wg_kernel: dW[k, f] over (pixel, image) reduction.
+// -------------------------------------------------------------------------------------------------
+struct WGParams {
+  const float* src;   // layer input  (N, SH*SW*C)
+  const float* dout;  // output deriv (N, M*F), M = GY*GX
+  float* dst;         // dW (F, K)  column-major: dst[f + F*k]
+  float* partial;     // [splits][K][F]
+  int K, F, N;
+  int GX, M;
+  int TX, TYX;
+  int SH, SW;
+  int ssy, ssx, y0, x0;
+  int nchunk;         // ceil(N/32) image chunks per pixel
+  int chunks_total;   // M*nchunk
+  int chunks_per_split;
+  int splits;
+  int k_tiles, f_tiles;
+  float scaleTargets, scaleOutput;
+};
+
+constexpr int WG_NB = 32;          // images per stage
+constexpr int WG_PITCH = WG_NB + 4;  // conflict-free ds_read_b128 across rows
+
+template <int WM, int WN, int MT, int NTL, bool VEC>
+__global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int KT = WM * MT * 32;   // k-columns (D rows) per block
+  constexpr int FT = WN * NTL * 32;  // filters (D cols / lanes) per block
+  constexpr int A_STAGE = KT * WG_PITCH, B_STAGE = FT * WG_PITCH;
+  constexpr int NA = (KT * 8 + NT - 1) / NT, NB = (FT * 8 + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * A_STAGE;
+
+  const int tiles = p.k_tiles * p.f_tiles;
+  const int L = blockIdx.x;
+  if (L >= tiles) return;
+  const int f_tile = L % p.f_tiles, k_tile = L / p.f_tiles;
+  const int split = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int kc0 = k_tile * KT, f0 = f_tile * FT;
+  const int N = p.N;
+
+  // A slots: one k-column each (fixed for the whole kernel)
+  int a_choff[NA], a_ta[NA], a_tb[NA], a_n[NA], a_lds[NA];
+  bool a_ok[NA];
+#pragma unroll
+  for (int it = 0; it < NA; ++it) {
+    const int idx = tid + it * NT;
+    const int row = idx >> 3, c4 = idx & 7;
+    const int k = kc0 + row;
+    const bool ok = idx < KT * 8 && k < p.K;
+    const int kk = ok ? k : 0;
+    const int ch = kk / p.TYX, tap = kk - ch * p.TYX;
+    a_ta[it] = tap / p.TX;
+    a_tb[it] = tap - a_ta[it] * p.TX;
+    a_choff[it] = ch * p.SH * p.SW;
+    a_n[it] = 4 * c4;
+    a_ok[it] = ok;
+    a_lds[it] = row * WG_PITCH + 4 * c4;
+  }
+  int b_f[NB], b_n[NB], b_lds[NB];
+  bool b_ok[NB];
+#pragma unroll
+  for (int it = 0; it < NB; ++it) {
+    const int idx = tid + it * NT;
+    const int row = idx >> 3, c4 = idx & 7;
+    b_f[it] = f0 + row;
+    b_ok[it] = idx < FT * 8 && b_f[it] < p.F;
+    b_n[it] = 4 * c4;
+    b_lds[it] = row * WG_PITCH + 4 * c4;
+  }
+
+  const int cbeg = split * p.chunks_per_split;
+  int cend = cbeg + p.chunks_per_split;
+  if (cend > p.chunks_total) cend = p.chunks_total;
+
+  f32x4 ra[NA], rb[NB];
+  auto fetch = [&](int c) {
+    const int m = c / p.nchunk, nc = c - m * p.nchunk;
+    const int oy = m / p.GX, ox = m - oy * p.GX;
+    const int ysb = oy * p.ssy + p.y0, xsb = ox * p.ssx + p.x0;
+    const int nb = nc * WG_NB;
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int ys = ysb + a_ta[it], xs = xsb + a_tb[it];
+      const int n = nb + a_n[it];
+      if (a_ok[it] && ys >= 0 && ys < p.SH && xs >= 0 && xs < p.SW) {
+        const float* sp = p.src + ((size_t)(a_choff[it] + ys * p.SW + xs)) * N + n;
+        if (VEC) {
+          if (n < N) v = ld4(sp);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < N) v[e] = sp[e];
+        }
+      }
+      ra[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int n = nb + b_n[it];
+      if (b_ok[it]) {
+        const float* dp = p.dout + ((size_t)b_f[it] * p.M + m) * N + n;
+        if (VEC) {
+          if (n < N) v = ld4(dp);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < N) v[e] = dp[e];
+        }
+      }
+      rb[it] = v;
+    }
+  };
+  auto stash = [&](int buf) {
+    float* as = As + buf * A_STAGE;
+    float* bs = Bs + buf * B_STAGE;
+#pragma unroll
+    for (int it = 0; it < NA; ++it)
+      if (tid + it * NT < KT * 8) st4(as + a_lds[it], ra[it]);
+#pragma unroll
+    for (int it = 0; it < NB; ++it)
+      if (tid + it * NT < FT * 8) st4(bs + b_lds[it], rb[it]);
+  };
+
+  f32x16 acc[MT][NTL];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int u = 0; u < NTL; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+
+  if (cend > cbeg) {
+    fetch(cbeg);
+    stash(0);
+  }
+  __syncthreads();
+  for (int c = cbeg; c < cend; ++c) {
+    const int buf = (c - cbeg) & 1;
+    if (c + 1 < cend) fetch(c + 1);
+    const float* ar = As + buf * A_STAGE + (wm * MT * 32 + li) * WG_PITCH + 4 * lh;
+    const float* br = Bs + buf * B_STAGE + (wn * NTL * 32 + li) * WG_PITCH + 4 * lh;
+#pragma unroll
+    for (int q = 0; q < WG_NB / 8; ++q) {
+      f32x4 a4[MT], b4[NTL];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) a4[t] = ld4(ar + t * 32 * WG_PITCH + 8 * q);
+#pragma unroll
+      for (int u = 0; u < NTL; ++u) b4[u] = ld4(br + u * 32 * WG_PITCH + 8 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int u = 0; u < NTL; ++u)
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t][e], b4[u][e], acc[t][u], 0, 0, 0);
+    }
+    if (c + 1 < cend) stash(buf ^ 1);
+    __syncthreads();
+  }
+
+  const bool fin = p.splits == 1;
+  float* out = fin ? p.dst : p.partial + (size_t)split * p.K * p.F;
+#pragma unroll
+  for (int u = 0; u < NTL; ++u) {
+    const int f = f0 + wn * NTL * 32 + u * 32 + li;
+    if (f >= p.F) continue;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int k = kc0 + wm * MT * 32 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        if (k >= p.K) continue;
+        float* dp = out + (size_t)k * p.F + f;
+        float v = acc[t][u][reg];
+        if (fin) {
+          v *= p.scaleOutput;
+          if (p.scaleTargets != 0.f) v = p.scaleTargets * (*dp) + v;
+        }
+        *dp = v;
+      }
+    }
+  }
+}
+
+__global__ void wg_reduce_kernel(float* __restrict__ dst, const float* __restrict__ partial, size_t total, int splits,
+                                 float scaleTargets, float scaleOutput) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += partial[(size_t)k * total + i];
+    s *= scaleOutput;
+    if (scaleTargets != 0.f) s = scaleTargets * dst[i] + s;
+    dst[i] = s;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// host-side dispatch
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kTargetBlocks = 512;  // ~2 resident blocks per CU
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename Kern>
+void allow_big_lds(Kern kern, size_t lds) {
+  // >64 KiB of dynamic LDS needs an explicit opt-in once per kernel.
+  if (lds > 64 * 1024) CHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+}
+
+// Launch one gather-GEMM.  `dst_elems` > 0 means the launch covers the whole destination matrix,
+// which makes a split-K (slab per split + deterministic reduce) legal.
+template <int WR, int WC, int MT, bool AK>
+void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
+  constexpr int ROWS = WR * MT * 32;
+  constexpr int A_STAGE = AK ? ROWS * (BK + 4) : BK * ROWS;
+  constexpr int B_STAGE = WC * BK * 128;
+  const size_t lds = sizeof(float) * 2 * (A_STAGE + B_STAGE);
+  p.row_tiles = divup(p.R, ROWS);
+  p.col_tiles = divup(p.ncols, WC);
+  const int tiles = p.row_tiles * p.col_tiles;
+  const int kchunks = divup(p.K, BK);
+  int splits = 1;
+  if (dst_elems > 0 && kchunks >= 32 && tiles < kTargetBlocks / 2) {
+    splits = kTargetBlocks / tiles;
+    if (splits > kchunks / 16) splits = kchunks / 16;
+    if (splits > 32) splits = 32;
+    if (splits < 1) splits = 1;
+  }
+  p.chunks_per_split = kchunks > 0 ? divup(kchunks, splits) : 1;
+  splits = kchunks > 0 ? divup(kchunks, p.chunks_per_split) : 1;
+  p.splits = splits;
+  p.slab = dst_elems;
+  p.partial = splits > 1 ? static_cast<float*>(workspace(sizeof(float) * dst_elems * splits)) : nullptr;
+  dim3 grid(((tiles + 7) / 8) * 8, splits);
+  dim3 block(WR * WC * 64);
+  if (vec) {
+    allow_big_lds(gg_kernel<WR, WC, MT, AK, true>, lds);
+    hipLaunchKernelGGL((gg_kernel<WR, WC, MT, AK, true>), grid, block, lds, stream(), p);
+  } else {
+    allow_big_lds(gg_kernel<WR, WC, MT, AK, false>, lds);
+    hipLaunchKernelGGL((gg_kernel<WR, WC, MT, AK, false>), grid, block, lds, stream(), p);
+  }
+  if (splits > 1) {
+    size_t nb = (dst_elems + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(gg_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream(), p.dst, p.partial, p.bias, dst_elems, p.slab,
+                       splits, (size_t)p.DP * p.N, p.scaleTargets, p.relu);
+  }
+}
+
+template <bool AK>
+void gg_run(GGParams& p, bool vec, size_t dst_elems) {
+  // pick the row tile (128/96/64/32) that pads the fewest rows; ties go to the larger tile.
+  int best = 128, best_pad = divup(p.R, 128) * 128;
+  const int cands[3] = {96, 64, 32};
+  for (int c : cands) {
+    const int pad = divup(p.R, c) * c;
+    if (pad < best_pad) {
+      best = c;
+      best_pad = pad;
+    }
+  }
+  switch (best) {
+    case 128: gg_launch_cfg<2, 2, 2, AK>(p, vec, dst_elems); break;   // 128 rows x 2 wave-columns
+    case 96: gg_launch_cfg<3, 2, 1, AK>(p, vec, dst_elems); break;    //  96 rows x 2 (6 waves)
+    case 64: gg_launch_cfg<2, 2, 1, AK>(p, vec, dst_elems); break;    //  64 rows x 2
+    default: gg_launch_cfg<1, 4, 1, AK>(p, vec, dst_elems); break;    //  32 rows x 4
+  }
+}
+
+template <int WM, int WN, int MT, int NTL>
+void wg_launch_cfg(WGParams& p, bool vec) {
+  constexpr int KT = WM * MT * 32, FT = WN * NTL * 32;
+  const size_t lds = sizeof(float) * 2 * (KT + FT) * WG_PITCH;
+  p.k_tiles = divup(p.K, KT);
+  p.f_tiles = divup(p.F, FT);
+  const int tiles = p.k_tiles * p.f_tiles;
+  const size_t total = (size_t)p.K * p.F;
+  int splits = 1;
+  if (tiles < kTargetBlocks) {
+    splits = divup(kTargetBlocks, tiles);
+    const int max_by_len = p.chunks_total / 16 > 0 ? p.chunks_total / 16 : 1;
+    if (splits > max_by_len) splits = max_by_len;
+    const size_t max_by_bytes = (size_t(256) << 20) / (total * sizeof(float)) + 1;
+    if ((size_t)splits > max_by_bytes) splits = (int)max_by_bytes;
+    if (splits > 1024) splits = 1024;
+  }
+  p.chunks_per_split = divup(p.chunks_total, splits);
+  splits = divup(p.chunks_total, p.chunks_per_split);
+  p.splits = splits;
+  p.partial = splits > 1 ? static_cast<float*>(workspace(sizeof(float) * total * splits)) : nullptr;
+  dim3 grid(tiles, splits), block(WM * WN * 64);
+  if (vec) {
+    allow_big_lds(wg_kernel<WM, WN, MT, NTL, true>, lds);
+    hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, true>), grid, block, lds, stream(), p);
+  } else {
+    allow_big_lds(wg_kernel<WM, WN, MT, NTL, false>, lds);
+    hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, false>), grid, block, lds, stream(), p);
+  }
+  if (splits > 1) {
+    size_t nb = (total + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream(), p.dst, p.partial, total, splits, p.scaleTargets,
+                       p.scaleOutput);
+  }
+}
+
+void wg_launch(WGParams& p, bool vec) {
+  // filter tile: fewest padded filters among 128/96/64/32; k tile 128, or 160 when that pads less.
+  int ft = 128, pad = divup(p.F, 128) * 128;
+  const int cands[3] = {96, 64, 32};
+  for (int c : cands) {
+    const int q = divup(p.F, c) * c;
+    if (q < pad) {
+      ft = c;
+      pad = q;
+    }
+  }
+  const bool k160 = divup(p.K, 160) * 160 < divup(p.K, 128) * 128;
+  if (ft == 128) wg_launch_cfg<2, 2, 2, 2>(p, vec);
+  else if (ft == 96 && k160) wg_launch_cfg<5, 1, 1, 3>(p, vec);
+  else if (ft == 96) wg_launch_cfg<4, 1, 1, 3>(p, vec);
+  else if (ft == 64) wg_launch_cfg<4, 1, 1, 2>(p, vec);
+  else wg_launch_cfg<4, 1, 1, 1>(p, vec);
+}
+
+struct ConvGeo {
+  int N, C, H, W, F, Ky, Kx, sy, sx, py, px, My, Mx;
+};
+
+ConvGeo conv_geo(const Shape4D* img, const Shape4D* flt, const Shape4D* out, const ConvDesc& d, const cudamat* mi,
+                 const cudamat* mf, const cudamat* mo) {
+  // Same consistency checks as the reference (cudamat_conv_gemm.cu:586-610).
+  ConvGeo g;
+  g.N = img->shape[0]; g.W = img->shape[1]; g.H = img->shape[2]; g.C = img->shape[3];
+  g.Mx = out->shape[1]; g.My = out->shape[2]; g.F = out->shape[3];
+  g.Ky = d.kernel_size_y; g.Kx = d.kernel_size_x; g.sy = d.stride_y; g.sx = d.stride_x;
+  g.py = d.padding_y; g.px = d.padding_x;
+  CHIP_REQUIRE(out->shape[0] == g.N);
+  CHIP_REQUIRE(d.num_input_channels == g.C && d.num_output_channels == g.F);
+  CHIP_REQUIRE(d.num_groups == 1);
+  CHIP_REQUIRE(d.input_channel_begin == 0 && (d.input_channel_end == 0 || d.input_channel_end == g.C));
+  CHIP_REQUIRE(d.output_channel_begin == 0 && (d.output_channel_end == 0 || d.output_channel_end == g.F));
+  CHIP_REQUIRE(flt->shape[0] == g.F && flt->shape[1] == g.Kx && flt->shape[2] == g.Ky && flt->shape[3] == g.C);
+  CHIP_REQUIRE(mi->size[0] == g.N && mi->size[1] == g.H * g.W * g.C);
+  CHIP_REQUIRE(mo->size[0] == g.N && mo->size[1] == g.My * g.Mx * g.F);
+  CHIP_REQUIRE(mf->size[0] == g.F && mf->size[1] == g.Ky * g.Kx * g.C);
+  CHIP_REQUIRE(g.My == (g.H - 2 * g.py - g.Ky) / g.sy + 1 && g.Mx == (g.W - 2 * g.px - g.Kx) / g.sx + 1);
+  CHIP_REQUIRE(d.kernel_size_t <= 1);
+  return g;
+}
+
+void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* targets, Shape4D* is, Shape4D* fs, Shape4D* ts,
+                  const ConvDesc& d, float scaleTargets, int relu) {
+  const ConvGeo g = conv_geo(is, fs, ts, d, images, filters, targets);
+  GGParams p{};
+  p.A = filters->data_device; p.src = images->data_device; p.dst = targets->data_device;
+  p.bias = bias ? bias->data_device : nullptr;
+  p.R = g.F; p.K = g.C * g.Ky * g.Kx; p.N = g.N; p.lda = g.F;
+  p.GX = g.Mx; p.G = g.My * g.Mx; p.TX = g.Kx; p.TYX = g.Ky * g.Kx;
+  p.SH = g.H; p.SW = g.W; p.ssy = g.sy; p.ssx = g.sx; p.y0 = g.py; p.x0 = g.px; p.dir = 1;
+  p.DW = g.Mx; p.DP = g.My * g.Mx; p.dsy = 1; p.dsx = 1; p.dy0 = 0; p.dx0 = 0;
+  p.nblk = divup(g.N, 128); p.ncols = p.G * p.nblk;
+  p.scaleTargets = scaleTargets; p.relu = relu;
+  const bool vec = g.N % 4 == 0 && g.F % 4 == 0 && aligned16(p.A) && aligned16(p.src) && aligned16(p.dst);
+  gg_run<false>(p, vec, (size_t)g.N * p.DP * g.F);
+  note_kernel("gg_kernel(fprop)", 2.0 * g.N * p.G * (double)g.F * p.K, p.row_tiles * p.col_tiles, p.splits);
+}
+
+}  // namespace
+}  // namespace chip
+
+using namespace chip;
+
+extern "C" {
+
+void convUpGemm(cudamat* images, cudamat* filters, cudamat* targets, Shape4D* is, Shape4D* fs, Shape4D* ts, ConvDesc d,
+                float scaleTargets) {
+  conv_up_impl(images, filters, nullptr, targets, is, fs, ts, d, scaleTargets, 0);
+}
+
+void convUp(cudamat* images, cudamat* filters, cudamat* targets, Shape4D* is, Shape4D* fs, Shape4D* ts, ConvDesc d,
+            float scaleTargets) {
+  conv_up_impl(images, filters, nullptr, targets, is, fs, ts, d, scaleTargets, 0);
+}
+
+void convUpBiasAct(cudamat* images, cudamat* filters, cudamat* bias, cudamat* targets, Shape4D* is, Shape4D* fs, Shape4D* ts,
+                   ConvDesc d, float scaleTargets, int relu) {
+  if (bias) CHIP_REQUIRE(bias->size[0] * bias->size[1] == d.num_output_channels);
+  conv_up_impl(images, filters, bias, targets, is, fs, ts, d, scaleTargets, relu);
+}
+
+void convDownGemm(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* ds, Shape4D* fs, Shape4D* ts, ConvDesc d,
+                  float scaleTargets) {
+  const ConvGeo g = conv_geo(ts, fs, ds, d, targets, filters, derivs);
+  // one launch per stride class (cy,cx): input rows iy with (iy - pad) % sy == cy share the tap set
+  // ky = cy + sy*a; their sources are oy = (iy - pad - cy)/sy - a  (pad = ConvDesc padding, <= 0).
+  float* wt = static_cast<float*>(workspace(sizeof(float) * (size_t)g.C * g.F * g.Ky * g.Kx + 256 * g.sy * g.sx));
+  size_t woff = 0;
+  double flops = 0;
+  int blocks = 0;
+  for (int cy = 0; cy < g.sy; ++cy) {
+    for (int cx = 0; cx < g.sx; ++cx) {
+      const int TYc = cy < g.Ky ? divup(g.Ky - cy, g.sy) : 0;
+      const int TXc = cx < g.Kx ? divup(g.Kx - cx, g.sx) : 0;
+      // iy = cy + pad + sy*j >= 0  ->  j >= ceil((-pad - cy)/sy)
+      auto first_j = [](int c, int pad, int s) {
+        const int need = -pad - c;
+        return need > 0 ? (need + s - 1) / s : 0;
+      };
+      const int jy0 = first_j(cy, g.py, g.sy), jx0 = first_j(cx, g.px, g.sx);
+      const int iy0 = cy + g.py + g.sy * jy0, ix0 = cx + g.px + g.sx * jx0;
+      if (iy0 >= g.H || ix0 >= g.W) continue;
+      const int GY = (g.H - 1 - iy0) / g.sy + 1, GX = (g.W - 1 - ix0) / g.sx + 1;
+      float* wc = wt + woff;
+      const size_t welems = (size_t)g.C * g.F * TYc * TXc;
+      woff += (welems + 63) / 64 * 64;
+      if (welems > 0) {
+        int nb = (int)((welems + 255) / 256);
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(dgrad_filter_kernel, dim3(nb), dim3(256), 0, stream(), filters->data_device, wc, g.F, g.C, g.Ky,
+                           g.Kx, cy, cx, g.sy, g.sx, TYc, TXc);
+      }
+      GGParams p{};
+      p.A = wc; p.src = derivs->data_device; p.dst = targets->data_device; p.bias = nullptr;
+      p.R = g.C; p.K = g.F * TYc * TXc; p.N = g.N; p.lda = g.C;
+      p.GX = GX; p.G = GY * GX; p.TX = TXc > 0 ? TXc : 1; p.TYX = TYc * TXc > 0 ? TYc * TXc : 1;
+      p.SH = g.My; p.SW = g.Mx; p.ssy = 1; p.ssx = 1; p.y0 = jy0; p.x0 = jx0; p.dir = -1;
+      p.DW = g.W; p.DP = g.H * g.W; p.dsy = g.sy; p.dsx = g.sx; p.dy0 = iy0; p.dx0 = ix0;
+      p.nblk = divup(g.N, 128); p.ncols = p.G * p.nblk;
+      p.scaleTargets = scaleTargets; p.relu = 0;
+      const bool vec = g.N % 4 == 0 && g.C % 4 == 0 && aligned16(p.src) && aligned16(p.dst);
+      gg_run<false>(p, vec, 0);
+      flops += 2.0 * g.N * p.G * (double)g.C * p.K;
+      blocks += p.row_tiles * p.col_tiles;
+    }
+  }
+  note_kernel("gg_kernel(dgrad)", flops, blocks, 1);
+}
+
+void convDown(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* ds, Shape4D* fs, Shape4D* ts, ConvDesc d,
+              float scaleTargets) {
+  convDownGemm(derivs, filters, targets, ds, fs, ts, d, scaleTargets);
+}
+
+void convOutpGemm(cudamat* images, cudamat* derivs, cudamat* targets, Shape4D* is, Shape4D* ds, Shape4D* ts, ConvDesc d,
+                  float scaleTargets, float scaleOutput) {
+  const ConvGeo g = conv_geo(is, ts, ds, d, images, targets, derivs);
+  WGParams p{};
+  p.src = images->data_device; p.dout = derivs->data_device; p.dst = targets->data_device;
+  p.K = g.C * g.Ky * g.Kx; p.F = g.F; p.N = g.N;
+  p.GX = g.Mx; p.M = g.My * g.Mx; p.TX = g.Kx; p.TYX = g.Ky * g.Kx; p.SH = g.H; p.SW = g.W;
+  p.ssy = g.sy; p.ssx = g.sx; p.y0 = g.py; p.x0 = g.px;
+  p.nchunk = divup(g.N, WG_NB); p.chunks_total = p.M * p.nchunk;
+  p.scaleTargets = scaleTargets; p.scaleOutput = scaleOutput;
+  const bool vec = g.N % 4 == 0 && aligned16(p.src) && aligned16(p.dout);
+  wg_launch(p, vec);
+  note_kernel("wg_kernel(wgrad)", 2.0 * g.N * p.M * (double)g.F * p.K, p.k_tiles * p.f_tiles, p.splits);
+}
+
+void convOutp(cudamat* images, cudamat* derivs, cudamat* targets, Shape4D* is, Shape4D* ds, Shape4D* ts, ConvDesc d,
+              int /*partialSumY*/, int /*partialSumX*/, float scaleTargets, float scaleOutput) {
+  convOutpGemm(images, derivs, targets, is, ds, ts, d, scaleTargets, scaleOutput);
+}
+
+// target = beta*target + alpha*op(mat1)*op(mat2)   (cudamat.cu:2130-2152).
+// The three shapes fc_edge.cc uses keep the image index as the contiguous dimension of the
+// activation operand, so they are the 1-pixel cases of the conv kernels:
+//   NT: out(N,F)  = in(N,D)  * W(F,D)^T      -> gg_kernel, A = W   (r-contiguous)
+//   NN: din(N,D)  = dout(N,F)* W(F,D)        -> gg_kernel, A = W   (k-contiguous)
+//   TN: dW(F,D)   = dout(N,F)^T * in(N,D)    -> wg_kernel
+int dotBiasAct(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target, float beta, float alpha, int relu) {
+  if (!mat1->on_device || !mat2->on_device || !target->on_device) return ERROR_NOT_ON_DEVICE;
+  const int t1 = mat1->is_trans, t2 = mat2->is_trans;
+  const int m = t1 ? mat1->size[1] : mat1->size[0], k1 = t1 ? mat1->size[0] : mat1->size[1];
+  const int k2 = t2 ? mat2->size[1] : mat2->size[0], n = t2 ? mat2->size[0] : mat2->size[1];
+  if (m != target->size[0] || n != target->size[1] || k1 != k2) return ERROR_INCOMPATIBLE_DIMENSIONS;
+  if (target->is_trans) return ERROR_TRANSPOSED;
+  const int K = k1;
+  if (!t1) {
+    // activations (m = N images) x weights
+    if (alpha != 1.0f) return ERROR_UNSUPPORTED;
+    GGParams p{};
+    p.src = mat1->data_device; p.dst = target->data_device; p.bias = bias ? bias->data_device : nullptr;
+    p.A = mat2->data_device;
+    p.R = n; p.K = K; p.N = m; p.lda = mat2->size[0];
+    p.GX = 1; p.G = 1; p.TX = 1; p.TYX = 1; p.SH = 1; p.SW = 1; p.ssy = 1; p.ssx = 1; p.y0 = 0; p.x0 = 0; p.dir = 1;
+    p.DW = 1; p.DP = 1; p.dsy = 1; p.dsx = 1; p.dy0 = 0; p.dx0 = 0;
+    p.nblk = divup(m, 128); p.ncols = p.nblk;
+    p.scaleTargets = beta; p.relu = relu;
+    const bool base_vec = m % 4 == 0 && aligned16(p.src) && aligned16(p.dst) && aligned16(p.A);
+    if (t2) {   // NT: A[r=f + F*k=d]
+      gg_run<false>(p, base_vec && n % 4 == 0, (size_t)m * n);
+    } else {    // NN: A[k=f + F*r=d]
+      gg_run<true>(p, base_vec && K % 4 == 0 && mat2->size[0] % 4 == 0, (size_t)m * n);
+    }
+    note_kernel(t2 ? "gg_kernel(fc NT)" : "gg_kernel(fc NN)", 2.0 * m * (double)n * K, p.row_tiles * p.col_tiles, p.splits);
+    return launch_status();
+  }
+  if (t1 && !t2) {
+    if (bias || relu) return ERROR_UNSUPPORTED;
+    // TN: target(m=F, n=D)[f + F*d] = sum_i mat1[i + N*f] * mat2[i + N*d], i over N images
+    WGParams p{};
+    p.src = mat2->data_device; p.dout = mat1->data_device; p.dst = target->data_device;
+    p.K = n; p.F = m; p.N = K;
+    p.GX = 1; p.M = 1; p.TX = 1; p.TYX = 1; p.SH = 1; p.SW = 1; p.ssy = 1; p.ssx = 1; p.y0 = 0; p.x0 = 0;
+    p.nchunk = divup(K, WG_NB); p.chunks_total = p.nchunk;
+    p.scaleTargets = beta; p.scaleOutput = alpha;
+    const bool vec = K % 4 == 0 && aligned16(p.src) && aligned16(p.dout);
+    wg_launch(p, vec);
+    note_kernel("wg_kernel(fc TN)", 2.0 * m * (double)n * K, p.k_tiles * p.f_tiles, p.splits);
+    return launch_status();
+  }
+  return ERROR_UNSUPPORTED;  // T,T never occurs on the hot path
+}
+
+int dot(cudamat* mat1, cudamat* mat2, cudamat* target, float beta, float alpha) {
+  return dotBiasAct(mat1, mat2, nullptr, target, beta, alpha, 0);
+}
+
+}  // extern "C"

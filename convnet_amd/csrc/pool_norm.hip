@@ -1,0 +1,342 @@
+// Max/avg pooling (+undo) and cross-map response normalisation (+undo) on the CHWN layout.
+// Reference: cudamat/cudamat_conv_gemm.cu:153-300 (kPool/kAvgPoolUndo/kMaxPoolUndo, scatter +
+// atomicAdd) and :438-540 (kCrossMapDenoms/kCrossMapRNorm/kCrossMapRNormUndo); semantics pinned by
+// the CPU oracle (src/CPUMatrix.cc:574-827, eigenmat/cpumat_conv.cc:462-560).
+// These are HBM-bound: every kernel is a pure *gather* (one lane owns 4 consecutive images of one
+// output element, float4 in / float4 out, no atomics), so the traffic is the algorithmic
+// read-once/write-once bytes plus L2-absorbed window overlap.
+#include <cfloat>
+
+#include "common.h"
+
+namespace chip {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct PoolGeo {
+  int N, C, H, W, Ky, Kx, sy, sx, py, px, My, Mx;
+  int nvec;  // ceil(N/4)
+};
+
+__device__ __forceinline__ f32x4 ldv(const float* p, int n, int N, bool vec) {
+  if (vec) return *reinterpret_cast<const f32x4*>(p);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (n + e < N) v[e] = p[e];
+  return v;
+}
+__device__ __forceinline__ void stv(float* p, f32x4 v, int n, int N, bool vec) {
+  if (vec) {
+    *reinterpret_cast<f32x4*>(p) = v;
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (n + e < N) p[e] = v[e];
+}
+
+// work item = (channel c, output pixel m, image quad q); q fastest so a wave reads 1 KiB runs.
+template <bool MAX>
+__global__ void pool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, PoolGeo g, float st, float so, bool vec) {
+  const size_t total = (size_t)g.C * g.My * g.Mx * g.nvec;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % g.nvec);
+    size_t r = i / g.nvec;
+    const int ox = (int)(r % g.Mx);
+    r /= g.Mx;
+    const int oy = (int)(r % g.My);
+    const int c = (int)(r / g.My);
+    const int n = 4 * q;
+    const int y0 = max(0, oy * g.sy + g.py), y1 = min(g.H, oy * g.sy + g.py + g.Ky);
+    const int x0 = max(0, ox * g.sx + g.px), x1 = min(g.W, ox * g.sx + g.px + g.Kx);
+    f32x4 acc = MAX ? f32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX} : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) {
+        const f32x4 v = ldv(in + ((size_t)(c * g.H + y) * g.W + x) * g.N + n, n, g.N, vec);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = MAX ? (acc[e] < v[e] ? v[e] : acc[e]) : acc[e] + v[e];
+      }
+    if (!MAX) {
+      const float cnt = (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = acc[e] / cnt;
+    }
+    float* op = out + ((size_t)(c * g.My + oy) * g.Mx + ox) * g.N + n;
+    f32x4 res = so * acc;
+    if (st != 0.f) res = st * ldv(op, n, g.N, vec) + res;
+    stv(op, res, n, g.N, vec);
+  }
+}
+
+__device__ __forceinline__ void cover(int i, int pad, int k, int s, int M, int& lo, int& hi) {
+  // pooled coordinates whose window covers input coordinate i (src/CPUMatrix.cc:669-673)
+  lo = (i - pad < k) ? 0 : (i - pad - k) / s + 1;
+  hi = min(M, 1 + (i - pad) / s);
+}
+
+// work item = (c, input pixel, image quad).  MAX: d_in += d_out[o] for every covering o whose max
+// equals this input (all ties count — SURVEY.md fact 9).  AVG: d_in += d_out[o]/|clipped window o|.
+template <bool MAX>
+__global__ void pool_undo_kernel(const float* __restrict__ images, const float* __restrict__ grads, const float* __restrict__ acts,
+                                 float* __restrict__ out, PoolGeo g, float st, bool vec) {
+  const size_t total = (size_t)g.C * g.H * g.W * g.nvec;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % g.nvec);
+    size_t r = i / g.nvec;
+    const int ix = (int)(r % g.W);
+    r /= g.W;
+    const int iy = (int)(r % g.H);
+    const int c = (int)(r / g.H);
+    const int n = 4 * q;
+    int oy0, oy1, ox0, ox1;
+    cover(iy, g.py, g.Ky, g.sy, g.My, oy0, oy1);
+    cover(ix, g.px, g.Kx, g.sx, g.Mx, ox0, ox1);
+    const bool inside = ix < g.px + g.sx * (g.Mx - 1) + g.Kx && iy < g.py + g.sy * (g.My - 1) + g.Ky;
+    const size_t t = ((size_t)(c * g.H + iy) * g.W + ix) * g.N + n;
+    f32x4 img = {0.f, 0.f, 0.f, 0.f};
+    if (MAX) img = ldv(images + t, n, g.N, vec);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (inside)
+      for (int oy = oy0; oy < oy1; ++oy) {
+        const float ry = fminf((float)g.H, (float)(g.py + oy * g.sy + g.Ky)) - fmaxf(0.f, (float)(g.py + oy * g.sy));
+        for (int ox = ox0; ox < ox1; ++ox) {
+          const size_t o = ((size_t)(c * g.My + oy) * g.Mx + ox) * g.N + n;
+          const f32x4 gv = ldv(grads + o, n, g.N, vec);
+          if (MAX) {
+            const f32x4 av = ldv(acts + o, n, g.N, vec);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += (img[e] == av[e]) ? gv[e] : 0.f;
+          } else {
+            const float rx = fminf((float)g.W, (float)(g.px + ox * g.sx + g.Kx)) - fmaxf(0.f, (float)(g.px + ox * g.sx));
+            const float inv = 1.0f / (rx * ry);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += gv[e] * inv;
+          }
+        }
+      }
+    if (st != 0.f) acc = st * ldv(out + t, n, g.N, vec) + acc;
+    stv(out + t, acc, n, g.N, vec);
+  }
+}
+
+// ---- cross-map response norm --------------------------------------------------------------------------
+// One lane owns 4 consecutive "locations" (a location = one (pixel, image); locations are
+// contiguous in memory) and walks the channel axis with the reference's sliding-window update
+// (subtract the channel that leaves, add the one that enters: cpumat_conv.cc:476-490), so the
+// fp32 rounding sequence per location is the oracle's.
+__device__ __forceinline__ void win_fwd(int j, int C, int sizeF, bool blocked, int& start, int& end) {
+  start = blocked ? (j / sizeF) * sizeF : -sizeF / 2 + j;
+  end = min(C, start + sizeF);
+  start = max(0, start);
+}
+__device__ __forceinline__ void win_bwd(int j, int C, int sizeF, bool blocked, int& start, int& end) {
+  start = blocked ? (j / sizeF) * sizeF : -sizeF + sizeF / 2 + j + 1;
+  end = min(C, start + sizeF);
+  start = max(0, start);
+}
+
+__global__ void rnorm_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, size_t locs, int C, int sizeF, float addScale,
+                                 float powScale, bool blocked, bool vec) {
+  const size_t nq = (locs + 3) >> 2;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+    const size_t l = q << 2;
+    const int rem = (int)min((size_t)4, locs - l);
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    int ps = 0, pe = 0;
+    for (int j = 0; j < C; ++j) {
+      int s, e;
+      win_fwd(j, C, sizeF, blocked, s, e);
+      for (int i = ps; i < s; ++i) {
+        const f32x4 v = ldv(in + (size_t)i * locs + l, 0, rem, vec);
+        sum = sum - v * v;
+      }
+      for (int i = pe; i < e; ++i) {
+        const f32x4 v = ldv(in + (size_t)i * locs + l, 0, rem, vec);
+        sum = sum + v * v;
+      }
+      const f32x4 x = ldv(in + (size_t)j * locs + l, 0, rem, vec);
+      f32x4 y;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) y[t] = x[t] * powf(1.f + addScale * sum[t], -powScale);
+      stv(out + (size_t)j * locs + l, y, 0, rem, vec);
+      ps = s;
+      pe = e;
+    }
+  }
+}
+
+// pass 1 of undo: den = (1+a*sum)^(-b-1); prod = dout*in*den; scaled = dout*den^(b/(b+1))
+__global__ void rnorm_undo1_kernel(const float* __restrict__ dout, const float* __restrict__ in, float* __restrict__ prod,
+                                   float* __restrict__ scaled, size_t locs, int C, int sizeF, float addScale, float powScale, bool blocked,
+                                   bool vec) {
+  const size_t nq = (locs + 3) >> 2;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+    const size_t l = q << 2;
+    const int rem = (int)min((size_t)4, locs - l);
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    int ps = 0, pe = 0;
+    for (int j = 0; j < C; ++j) {
+      int s, e;
+      win_fwd(j, C, sizeF, blocked, s, e);
+      for (int i = ps; i < s; ++i) {
+        const f32x4 v = ldv(in + (size_t)i * locs + l, 0, rem, vec);
+        sum = sum - v * v;
+      }
+      for (int i = pe; i < e; ++i) {
+        const f32x4 v = ldv(in + (size_t)i * locs + l, 0, rem, vec);
+        sum = sum + v * v;
+      }
+      const f32x4 x = ldv(in + (size_t)j * locs + l, 0, rem, vec);
+      const f32x4 d = ldv(dout + (size_t)j * locs + l, 0, rem, vec);
+      f32x4 pr, sc;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float den = powf(1.f + addScale * sum[t], -powScale - 1.f);
+        pr[t] = d[t] * x[t] * den;
+        sc[t] = d[t] * powf(den, powScale / (powScale + 1.f));
+      }
+      stv(prod + (size_t)j * locs + l, pr, 0, rem, vec);
+      stv(scaled + (size_t)j * locs + l, sc, 0, rem, vec);
+      ps = s;
+      pe = e;
+    }
+  }
+}
+
+// pass 2: target_j = scaled_j - 2ab * in_j * sum_{i in win^-1(j)} prod_i
+__global__ void rnorm_undo2_kernel(const float* __restrict__ in, const float* __restrict__ prod, const float* __restrict__ scaled,
+                                   float* __restrict__ out, size_t locs, int C, int sizeF, float addScale, float powScale, bool blocked,
+                                   bool vec) {
+  const size_t nq = (locs + 3) >> 2;
+  const float k2 = 2 * addScale * powScale;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+    const size_t l = q << 2;
+    const int rem = (int)min((size_t)4, locs - l);
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    int ps = 0, pe = 0;
+    for (int j = 0; j < C; ++j) {
+      int s, e;
+      win_bwd(j, C, sizeF, blocked, s, e);
+      for (int i = ps; i < s; ++i) sum = sum - ldv(prod + (size_t)i * locs + l, 0, rem, vec);
+      for (int i = pe; i < e; ++i) sum = sum + ldv(prod + (size_t)i * locs + l, 0, rem, vec);
+      const f32x4 x = ldv(in + (size_t)j * locs + l, 0, rem, vec);
+      const f32x4 sc = ldv(scaled + (size_t)j * locs + l, 0, rem, vec);
+      f32x4 y;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) y[t] = sc[t] - k2 * x[t] * sum[t];
+      stv(out + (size_t)j * locs + l, y, 0, rem, vec);
+      ps = s;
+      pe = e;
+    }
+  }
+}
+
+namespace {
+
+inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+inline int grid_for(size_t items) {
+  size_t b = (items + 255) / 256;
+  if (b > 4096) b = 4096;
+  return b ? (int)b : 1;
+}
+
+PoolGeo pool_geo(const Shape4D* in, const Shape4D* out, const ConvDesc& d, const cudamat* mi, const cudamat* mo) {
+  PoolGeo g;
+  g.N = in->shape[0]; g.W = in->shape[1]; g.H = in->shape[2]; g.C = in->shape[3];
+  g.Mx = out->shape[1]; g.My = out->shape[2];
+  g.Ky = d.kernel_size_y; g.Kx = d.kernel_size_x; g.sy = d.stride_y; g.sx = d.stride_x; g.py = d.padding_y; g.px = d.padding_x;
+  g.nvec = divup(g.N, 4);
+  CHIP_REQUIRE(out->shape[0] == g.N && out->shape[3] == g.C);
+  CHIP_REQUIRE(d.num_input_channels == g.C && d.num_output_channels == g.C);  // cudamat_conv_gemm.cu:1150-1160
+  CHIP_REQUIRE(mi->size[0] == g.N && mi->size[1] == g.H * g.W * g.C);
+  CHIP_REQUIRE(mo->size[0] == g.N && mo->size[1] == g.My * g.Mx * g.C);
+  CHIP_REQUIRE(g.My == (g.H - 2 * g.py - g.Ky) / g.sy + 1 && g.Mx == (g.W - 2 * g.px - g.Kx) / g.sx + 1);
+  return g;
+}
+
+template <bool MAX>
+void pool_fwd(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, const ConvDesc& d, float st, float so) {
+  const PoolGeo g = pool_geo(is, ts, d, images, targets);
+  const bool vec = g.N % 4 == 0 && a16(images->data_device) && a16(targets->data_device);
+  const size_t total = (size_t)g.C * g.My * g.Mx * g.nvec;
+  hipLaunchKernelGGL(pool_fwd_kernel<MAX>, dim3(grid_for(total)), dim3(256), 0, stream(), images->data_device, targets->data_device, g, st,
+                     so, vec);
+}
+
+template <bool MAX>
+void pool_undo(cudamat* images, cudamat* grads, cudamat* acts, cudamat* targets, Shape4D* in_shape, Shape4D* pooled_shape,
+               const ConvDesc& d, float st) {
+  const PoolGeo g = pool_geo(in_shape, pooled_shape, d, targets, grads);
+  const bool vec = g.N % 4 == 0 && a16(grads->data_device) && a16(targets->data_device) &&
+                   (!MAX || (a16(images->data_device) && a16(acts->data_device)));
+  const size_t total = (size_t)g.C * g.H * g.W * g.nvec;
+  hipLaunchKernelGGL(pool_undo_kernel<MAX>, dim3(grid_for(total)), dim3(256), 0, stream(), MAX ? images->data_device : nullptr,
+                     grads->data_device, MAX ? acts->data_device : nullptr, targets->data_device, g, st, vec);
+}
+
+}  // namespace
+}  // namespace chip
+
+using namespace chip;
+
+extern "C" {
+
+void MaxPoolGemm(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, ConvDesc d, float scaleTargets, float scaleOutput) {
+  pool_fwd<true>(images, targets, is, ts, d, scaleTargets, scaleOutput);
+}
+void AvgPoolGemm(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, ConvDesc d, float scaleTargets, float scaleOutput) {
+  pool_fwd<false>(images, targets, is, ts, d, scaleTargets, scaleOutput);
+}
+void MaxPool(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, ConvDesc d) { pool_fwd<true>(images, targets, is, ts, d, 0.f, 1.f); }
+void AvgPool(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, ConvDesc d) { pool_fwd<false>(images, targets, is, ts, d, 0.f, 1.f); }
+
+void MaxPoolUndoGemm(cudamat* images, cudamat* maxGrads, cudamat* maxActs, cudamat* targets, Shape4D* images_shape, Shape4D* maxGrads_shape,
+                     ConvDesc d, float scaleTargets) {
+  pool_undo<true>(images, maxGrads, maxActs, targets, images_shape, maxGrads_shape, d, scaleTargets);
+}
+void MaxPoolUndo(cudamat* images, cudamat* maxGrads, cudamat* maxActs, cudamat* targets, Shape4D* images_shape, Shape4D* maxGrads_shape,
+                 ConvDesc d, float scaleTargets) {
+  pool_undo<true>(images, maxGrads, maxActs, targets, images_shape, maxGrads_shape, d, scaleTargets);
+}
+void AvgPoolUndoGemm(cudamat* avgGrads, cudamat* targets, Shape4D* avgGrads_shape, Shape4D* targets_shape, ConvDesc d, float scaleTargets) {
+  pool_undo<false>(nullptr, avgGrads, nullptr, targets, targets_shape, avgGrads_shape, d, scaleTargets);
+}
+void AvgPoolUndo(cudamat* avgGrads, cudamat* targets, Shape4D* avgGrads_shape, Shape4D* targets_shape, ConvDesc d, float scaleTargets) {
+  pool_undo<false>(nullptr, avgGrads, nullptr, targets, targets_shape, avgGrads_shape, d, scaleTargets);
+}
+
+void ResponseNormCrossMapGemm(cudamat* images, cudamat* targets, int numFilters, int sizeF, float addScale, float powScale, bool blocked) {
+  const size_t total = numel(images);
+  CHIP_REQUIRE(numel(targets) == total && numFilters > 0 && total % numFilters == 0 && sizeF > 0);
+  const size_t locs = total / numFilters;
+  const bool vec = locs % 4 == 0 && a16(images->data_device) && a16(targets->data_device);
+  hipLaunchKernelGGL(rnorm_fwd_kernel, dim3(grid_for((locs + 3) / 4)), dim3(256), 0, stream(), images->data_device, targets->data_device, locs,
+                     numFilters, sizeF, addScale, powScale, blocked, vec);
+}
+void ResponseNormCrossMap(cudamat* images, cudamat* targets, int numFilters, int sizeF, float addScale, float powScale, bool blocked) {
+  ResponseNormCrossMapGemm(images, targets, numFilters, sizeF, addScale, powScale, blocked);
+}
+
+void ResponseNormCrossMapUndoGemm(cudamat* outGrads, cudamat* inputs, cudamat* targets, int numFilters, int sizeF, float addScale,
+                                  float powScale, bool blocked) {
+  const size_t total = numel(inputs);
+  CHIP_REQUIRE(numel(targets) == total && numel(outGrads) == total && numFilters > 0 && total % numFilters == 0 && sizeF > 0);
+  const size_t locs = total / numFilters;
+  const size_t padded = (total + 63) / 64 * 64;
+  float* prod = static_cast<float*>(workspace(sizeof(float) * padded * 2));
+  float* scaled = prod + padded;
+  const bool vec = locs % 4 == 0 && a16(outGrads->data_device) && a16(inputs->data_device) && a16(targets->data_device);
+  const int grid = grid_for((locs + 3) / 4);
+  hipLaunchKernelGGL(rnorm_undo1_kernel, dim3(grid), dim3(256), 0, stream(), outGrads->data_device, inputs->data_device, prod, scaled, locs,
+                     numFilters, sizeF, addScale, powScale, blocked, vec);
+  hipLaunchKernelGGL(rnorm_undo2_kernel, dim3(grid), dim3(256), 0, stream(), inputs->data_device, prod, scaled, targets->data_device, locs,
+                     numFilters, sizeF, addScale, powScale, blocked, vec);
+}
+void ResponseNormCrossMapUndo(cudamat* outGrads, cudamat* inputs, cudamat* /*acts*/, cudamat* targets, int numFilters, int sizeF,
+                              float addScale, float powScale, bool blocked) {
+  ResponseNormCrossMapUndoGemm(outGrads, inputs, targets, numFilters, sizeF, addScale, powScale, blocked);
+}
+
+}  // extern "C"

@@ -1,0 +1,232 @@
+// Library state, memory plumbing and views: the non-compute part of the cudamat ABI
+// (reference cudamat/cudamat.cu:40-160,360-640), re-done over the HIP runtime.
+#include <cstring>
+#include <string>
+
+#include "common.h"
+
+namespace chip {
+namespace {
+hipStream_t g_stream = nullptr;
+void* g_ws = nullptr;
+size_t g_ws_bytes = 0;
+std::string g_last_error;
+ConvnetHipKernelInfo g_info = {"none", 0.0, 0, 1};
+}  // namespace
+
+hipStream_t stream() { return g_stream; }
+
+void* workspace(size_t bytes) {
+  if (bytes <= g_ws_bytes) return g_ws;
+  // Grow: wait for in-flight users of the old arena, then replace it.  Rounded up generously so
+  // a training run reaches steady state after the first step.
+  CHIP_CHECK(hipStreamSynchronize(g_stream));
+  if (g_ws) CHIP_CHECK(hipFree(g_ws));
+  size_t want = ((bytes + (size_t(1) << 22)) >> 20) << 20;
+  CHIP_CHECK(hipMalloc(&g_ws, want));
+  g_ws_bytes = want;
+  return g_ws;
+}
+
+void set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
+
+void note_kernel(const char* name, double flops, int blocks, int split_k) {
+  g_info.name = name;
+  g_info.flops = flops;
+  g_info.grid_blocks = blocks;
+  g_info.split_k = split_k;
+}
+
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+  // dst (cols x rows, col-major) = src^T, src (rows x cols, col-major).  32x32 LDS tile (+1 pad).
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = bx + tx, c = by + j;
+    if (r < rows && c < cols) tile[j][tx] = src[(size_t)r + (size_t)rows * c];
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = by + tx, r = bx + j;
+    if (r < rows && c < cols) dst[(size_t)c + (size_t)cols * r] = tile[tx][j];
+  }
+}
+
+}  // namespace chip
+
+using namespace chip;
+
+extern "C" {
+
+int convnet_hip_init(int device_id) {
+  if (hipSetDevice(device_id) != hipSuccess) return CUDA_ERROR;
+  return 0;
+}
+
+void convnet_hip_shutdown(void) {
+  if (g_ws) {
+    hipStreamSynchronize(g_stream);
+    hipFree(g_ws);
+    g_ws = nullptr;
+    g_ws_bytes = 0;
+  }
+}
+
+void convnet_hip_set_stream(void* s) { g_stream = (hipStream_t)s; }
+void* convnet_hip_get_stream(void) { return (void*)g_stream; }
+
+int convnet_hip_reserve_workspace(size_t bytes) {
+  workspace(bytes);
+  return 0;
+}
+
+const char* convnet_hip_version(void) { return "convnet_hip 0.1 (gfx950, fp32 MFMA)"; }
+const char* get_last_cuda_error(void) { return g_last_error.c_str(); }
+
+int cuda_set_device(int deviceId) { return hipSetDevice(deviceId) == hipSuccess ? 0 : CUDA_ERROR; }
+
+void cuda_sync_threads(void) { CHIP_CHECK(hipStreamSynchronize(g_stream)); }
+
+void convnet_hip_last_kernel_info(ConvnetHipKernelInfo* out) { *out = g_info; }
+
+int allocate_device_memory(cudamat* mat) {
+  const size_t bytes = numel(mat) * sizeof(float);
+  if (hipMalloc((void**)&mat->data_device, bytes ? bytes : 4) != hipSuccess) {
+    set_last_error("hipMalloc failed");
+    return CUDA_ERROR;
+  }
+  mat->on_device = 1;
+  return 0;
+}
+
+int free_device_memory(cudamat* mat) {
+  if (mat->owns_data && mat->on_device) {
+    if (hipFree(mat->data_device) != hipSuccess) return CUDA_ERROR;
+    mat->on_device = 0;
+    mat->data_device = nullptr;
+  }
+  return 0;
+}
+
+int copy_to_host(cudamat* mat) {
+  if (!mat->on_device) return ERROR_NOT_ON_DEVICE;
+  const size_t bytes = numel(mat) * sizeof(float);
+  if (hipMemcpyAsync(mat->data_host, mat->data_device, bytes, hipMemcpyDeviceToHost, g_stream) != hipSuccess) return CUDA_ERROR;
+  if (hipStreamSynchronize(g_stream) != hipSuccess) return CUDA_ERROR;
+  mat->on_host = 1;
+  return 0;
+}
+
+int copy_to_device(cudamat* mat) {
+  if (!mat->on_device) {
+    int rc = allocate_device_memory(mat);
+    if (rc) return rc;
+  }
+  const size_t bytes = numel(mat) * sizeof(float);
+  if (hipMemcpyAsync(mat->data_device, mat->data_host, bytes, hipMemcpyHostToDevice, g_stream) != hipSuccess) return CUDA_ERROR;
+  if (hipStreamSynchronize(g_stream) != hipSuccess) return CUDA_ERROR;
+  return 0;
+}
+
+int copy_to_host_slice(cudamat* mat, size_t start, size_t end) {
+  if (!mat->on_device) return ERROR_NOT_ON_DEVICE;
+  if (end > (size_t)mat->size[1] || start > end) return ERROR_INCOMPATIBLE_DIMENSIONS;
+  const size_t off = start * mat->size[0], bytes = (end - start) * mat->size[0] * sizeof(float);
+  if (hipMemcpyAsync(mat->data_host + off, mat->data_device + off, bytes, hipMemcpyDeviceToHost, g_stream) != hipSuccess) return CUDA_ERROR;
+  return hipStreamSynchronize(g_stream) == hipSuccess ? 0 : CUDA_ERROR;
+}
+
+int copy_to_device_slice(cudamat* mat, size_t start, size_t end) {
+  if (!mat->on_device) return ERROR_NOT_ON_DEVICE;
+  if (end > (size_t)mat->size[1] || start > end) return ERROR_INCOMPATIBLE_DIMENSIONS;
+  const size_t off = start * mat->size[0], bytes = (end - start) * mat->size[0] * sizeof(float);
+  if (hipMemcpyAsync(mat->data_device + off, mat->data_host + off, bytes, hipMemcpyHostToDevice, g_stream) != hipSuccess) return CUDA_ERROR;
+  return hipStreamSynchronize(g_stream) == hipSuccess ? 0 : CUDA_ERROR;
+}
+
+int copy_on_device(cudamat* mat1, cudamat* mat2) {
+  if (mat1->size[0] != mat2->size[0] || mat1->size[1] != mat2->size[1]) return ERROR_INCOMPATIBLE_DIMENSIONS;
+  if (hipMemcpyAsync(mat2->data_device, mat1->data_device, numel(mat1) * sizeof(float), hipMemcpyDeviceToDevice, g_stream) != hipSuccess) return CUDA_ERROR;
+  return 0;
+}
+
+int copy_transpose(cudamat* source, cudamat* target) {
+  if (source->size[0] != target->size[1] || source->size[1] != target->size[0]) return ERROR_INCOMPATIBLE_DIMENSIONS;
+  const int rows = source->size[0], cols = source->size[1];
+  dim3 grid(divup(rows, 32), divup(cols, 32));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, g_stream, source->data_device, target->data_device, rows, cols);
+  return launch_status();
+}
+
+int reshape(cudamat* mat, int m, int n) {
+  if (m < 0 && n < 0) return ERROR_GENERIC;
+  const long long total = (long long)mat->size[0] * mat->size[1];
+  if (m < 0) m = (int)(total / n);
+  if (n < 0) n = (int)(total / m);
+  if (total != (long long)m * n) return ERROR_INCOMPATIBLE_DIMENSIONS;
+  mat->size[0] = m;
+  mat->size[1] = n;
+  return 0;
+}
+
+int get_slice(cudamat* source, cudamat* target, unsigned int first_col, unsigned int last_col) {
+  if (source->is_trans) return ERROR_TRANSPOSED;
+  if (!source->on_device) return ERROR_NOT_ON_DEVICE;
+  if (last_col > (unsigned)source->size[1] || first_col >= last_col) return ERROR_INCOMPATIBLE_DIMENSIONS;
+  const size_t rows = source->size[0];
+  target->data_host = source->data_host ? source->data_host + first_col * rows : nullptr;
+  target->data_device = source->data_device + first_col * rows;
+  target->on_device = 1;
+  target->on_host = 0;
+  target->size[0] = source->size[0];
+  target->size[1] = last_col - first_col;
+  target->is_trans = 0;
+  target->owns_data = 0;
+  target->tex_obj = 0;
+  return 0;
+}
+
+void init_from_array(cudamat* mat, float* data, int m, int n) {
+  mat->data_host = data;
+  mat->data_device = nullptr;
+  mat->size[0] = m;
+  mat->size[1] = n;
+  mat->on_device = 0;
+  mat->on_host = 1;
+  mat->is_trans = 0;
+  mat->owns_data = 1;
+  mat->tex_obj = 0;
+}
+
+int init_empty(cudamat* mat, int m, int n) {
+  mat->data_host = nullptr;
+  mat->size[0] = m;
+  mat->size[1] = n;
+  mat->on_host = 0;
+  mat->is_trans = 0;
+  mat->owns_data = 1;
+  mat->tex_obj = 0;
+  return allocate_device_memory(mat);
+}
+
+int write_at(cudamat* mat, int row, int col, float val) {
+  if (row < 0 || col < 0 || row >= mat->size[0] || col >= mat->size[1]) return ERROR_INCOMPATIBLE_DIMENSIONS;
+  if (hipMemcpyAsync(mat->data_device + (size_t)col * mat->size[0] + row, &val, sizeof(float), hipMemcpyHostToDevice, g_stream) != hipSuccess) return CUDA_ERROR;
+  return hipStreamSynchronize(g_stream) == hipSuccess ? 0 : CUDA_ERROR;
+}
+
+float read_from(cudamat* mat, int row, int col, int* err_code) {
+  *err_code = 0;
+  if (row < 0 || col < 0 || row >= mat->size[0] || col >= mat->size[1]) {
+    *err_code = ERROR_INCOMPATIBLE_DIMENSIONS;
+    return 0.f;
+  }
+  float v = 0.f;
+  if (hipMemcpyAsync(&v, mat->data_device + (size_t)col * mat->size[0] + row, sizeof(float), hipMemcpyDeviceToHost, g_stream) != hipSuccess ||
+      hipStreamSynchronize(g_stream) != hipSuccess)
+    *err_code = CUDA_ERROR;
+  return v;
+}
+
+}  // extern "C"

@@ -1,0 +1,252 @@
+/* convnet_hip.h — C ABI of libconvnet_hip.so: the MI355X (gfx950) implementation of
+ * TorontoDeepLearning/convnet's data-parallel training hot path.
+ *
+ * This is the reference's "seam #2" (SURVEY.md §8b): the extern "C" cudamat interface that
+ * src/matrix.cc and the cudamat ctypes modules bind.  Every entry point below keeps the reference's symbol name,
+ * argument order, argument meaning and error convention, so a build of the reference that links
+ * this library instead of libcudamat.so + libcudamat_conv_gemm.so needs no source change in
+ * the reference's edge / layer / optimizer.cc / convnet.cc.  Each declaration
+ * cites the reference interface it replaces.
+ *
+ * Plain C: pointers, ints, floats.  No torch / HIP types cross this boundary (hipStream_t is passed
+ * as void*).  All matrices are column-major fp32; activations are (num_images, X*Y*C) with the
+ * image index fastest ("CHWN"), filters (F, Kx*Ky*C)            — cudamat_conv_gemm.cuh:5-10.
+ * ConvDesc.padding_* hold the NEGATED pbtxt padding               — src/edge.cc:97-99.
+ *
+ * Error convention (cudamat.cuh:3-11): functions returning int give 0 or a negative ERROR_* code;
+ * the conv/pool/norm functions return void and abort the process on inconsistent shapes, as the
+ * reference does (cudamat_conv_gemm.cu:35-42,586-610).
+ */
+#ifndef CONVNET_HIP_H_
+#define CONVNET_HIP_H_
+
+#include <stdbool.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ERROR_INCOMPATIBLE_DIMENSIONS -1
+#define CUBLAS_ERROR -2   /* kept for numbering; never returned (no BLAS library is used) */
+#define CUDA_ERROR -3     /* any HIP runtime failure */
+#define VIEW_ERROR -4
+#define ERROR_TRANSPOSED -5
+#define ERROR_GENERIC -6
+#define ERROR_TRANSPOSEDNESS -7
+#define ERROR_NOT_ON_DEVICE -8
+#define ERROR_UNSUPPORTED -9
+
+/* Bit-identical to `struct cudamat` (cudamat/cudamat.cuh:28-37; ctypes mirror cudamat.py:127-135).
+ * `tex_obj` was a cudaTextureObject_t (64-bit); it is kept as an opaque 64-bit slot. */
+typedef struct cudamat {
+  float* data_host;
+  float* data_device;
+  int on_device;
+  int on_host;
+  int size[2];      /* size[0] = rows = leading dimension */
+  int is_trans;     /* 0 or 1; honoured by dot() only */
+  int owns_data;
+  unsigned long long tex_obj;
+} cudamat;
+typedef cudamat hipmat;
+
+/* cudamat/cudamat.cuh:86-107 (== eigenmat/common.h:4-27) */
+typedef struct Shape4D {
+  int shape[4];     /* {num_images, size_x, size_y, channels} — src/layer.cc:257-258 */
+} Shape4D;
+
+typedef struct ConvDesc {
+  int num_input_channels;
+  int num_output_channels;
+  int kernel_size_y;
+  int kernel_size_x;
+  int kernel_size_t;
+  int stride_y;
+  int stride_x;
+  int stride_t;
+  int padding_y;
+  int padding_x;
+  int padding_t;
+  int input_channel_begin;
+  int input_channel_end;
+  int output_channel_begin;
+  int output_channel_end;
+  int num_groups;
+} ConvDesc;
+
+/* ---- library state (new; the reference used the legacy default stream + per-call cudaMalloc) ---
+ * All work is enqueued on ONE current stream per host thread-less global (the reference is not
+ * thread-safe either).  Scratch (split-K partials, dgrad filter images) comes from a
+ * library-owned arena that only grows; nothing in the ABI passes a workspace. */
+int convnet_hip_init(int device_id);                 /* cuda_set_device + cublas_init (cudamat.cuh:93-96) */
+void convnet_hip_shutdown(void);                     /* cublas_shutdown */
+void convnet_hip_set_stream(void* hip_stream);       /* hipStream_t; NULL = default stream */
+void* convnet_hip_get_stream(void);
+int convnet_hip_reserve_workspace(size_t bytes);     /* optional pre-size (avoids growth mid-run) */
+const char* convnet_hip_version(void);
+const char* get_last_cuda_error(void);               /* cudamat.cuh:109 */
+int cuda_set_device(int deviceId);                   /* cudamat.cuh:116 */
+void cuda_sync_threads(void);                        /* cudamat.cuh:123 — synchronises the current stream */
+
+/* ---- memory / views (cudamat.cuh:124-153) -------------------------------------------------------- */
+int allocate_device_memory(cudamat* mat);
+int free_device_memory(cudamat* mat);
+int copy_to_host(cudamat* mat);
+int copy_to_device(cudamat* mat);
+int copy_to_host_slice(cudamat* mat, size_t start, size_t end);     /* column range */
+int copy_to_device_slice(cudamat* mat, size_t start, size_t end);
+int copy_on_device(cudamat* mat1, cudamat* mat2);                   /* mat2 = mat1 */
+int copy_transpose(cudamat* source, cudamat* target);
+int reshape(cudamat* mat, int m, int n);                            /* -1 allowed for one dim */
+int get_slice(cudamat* source, cudamat* target, unsigned int first_col, unsigned int last_col);
+void init_from_array(cudamat* mat, float* data, int m, int n);
+int init_empty(cudamat* mat, int m, int n);
+int write_at(cudamat* mat, int row, int col, float val);
+float read_from(cudamat* mat, int row, int col, int* err_code);
+
+/* ---- convolution: cudamat/cudamat_conv_gemm.cuh:36-49 ----------------------------------------------
+ * targets = scaleTargets*targets + conv(...).  scaleTargets is the reference's 0/1 accumulate flag but
+ * any value is honoured.  Implemented as implicit-GEMM on fp32 MFMA (no im2col buffer). */
+void convUpGemm(cudamat* images, cudamat* filters, cudamat* targets,
+                Shape4D* images_shape, Shape4D* filters_shape,
+                Shape4D* targets_shape, ConvDesc conv_desc,
+                float scaleTargets);
+void convDownGemm(cudamat* derivs, cudamat* filters, cudamat* targets,
+                  Shape4D* derivs_shape, Shape4D* filters_shape,
+                  Shape4D* targets_shape, ConvDesc conv_desc,
+                  float scaleTargets);
+void convOutpGemm(cudamat* images, cudamat* derivs, cudamat* targets,
+                  Shape4D* images_shape, Shape4D* derivs_shape,
+                  Shape4D* targets_shape, ConvDesc conv_desc,
+                  float scaleTargets, float scaleOutput);
+/* convnet2-style names of the same operations (cudamat/cudamat_conv.cuh:10-29); partialSum* are
+ * accepted and ignored (the split-K factor is chosen internally and reduced deterministically). */
+void convUp(cudamat* images, cudamat* filters, cudamat* targets,
+            Shape4D* images_shape, Shape4D* filters_shape, Shape4D* targets_shape,
+            ConvDesc conv_desc, float scaleTargets);
+void convDown(cudamat* derivs, cudamat* filters, cudamat* targets,
+              Shape4D* derivs_shape, Shape4D* filters_shape, Shape4D* targets_shape,
+              ConvDesc conv_desc, float scaleTargets);
+void convOutp(cudamat* images, cudamat* derivs, cudamat* targets,
+              Shape4D* images_shape, Shape4D* derivs_shape, Shape4D* targets_shape,
+              ConvDesc conv_desc, int partialSumY, int partialSumX, float scaleTargets,
+              float scaleOutput);
+
+/* ---- pooling: cudamat_conv_gemm.cuh:72-92 (and cudamat_conv.cuh:58-70) ------------------------------ */
+void MaxPoolGemm(cudamat* images, cudamat* targets, Shape4D* images_shape,
+                 Shape4D* targets_shape, ConvDesc conv_desc, float scaleTargets,
+                 float scaleOutput);
+void MaxPoolUndoGemm(cudamat* images, cudamat* maxGrads, cudamat* maxActs,
+                     cudamat* targets, Shape4D* images_shape,
+                     Shape4D* maxGrads_shape, ConvDesc conv_desc,
+                     float scaleTargets);
+void AvgPoolGemm(cudamat* images, cudamat* targets, Shape4D* images_shape,
+                 Shape4D* targets_shape, ConvDesc conv_desc, float scaleTargets,
+                 float scaleOutput);
+void AvgPoolUndoGemm(cudamat* avgGrads, cudamat* targets,
+                     Shape4D* avgGrads_shape, Shape4D* targets_shape,
+                     ConvDesc conv_desc, float scaleTargets);
+void MaxPool(cudamat* images, cudamat* targets, Shape4D* images_shape,
+             Shape4D* targets_shape, ConvDesc conv_desc);
+void AvgPool(cudamat* images, cudamat* targets, Shape4D* images_shape,
+             Shape4D* targets_shape, ConvDesc conv_desc);
+void MaxPoolUndo(cudamat* images, cudamat* maxGrads, cudamat* maxActs,
+                 cudamat* targets, Shape4D* images_shape, Shape4D* maxGrads_shape,
+                 ConvDesc conv_desc, float scaleTargets);
+void AvgPoolUndo(cudamat* avgGrads, cudamat* targets, Shape4D* avgGrads_shape,
+                 Shape4D* targets_shape, ConvDesc conv_desc, float scaleTargets);
+
+/* ---- cross-map response normalisation: cudamat_conv_gemm.cuh:100-106, cudamat_conv.cuh:35-42 --------- */
+void ResponseNormCrossMapGemm(cudamat* images, cudamat* targets, int numFilters, int sizeF,
+                              float addScale, float powScale, bool blocked);
+void ResponseNormCrossMapUndoGemm(cudamat* outGrads, cudamat* inputs, cudamat* targets,
+                                  int numFilters, int sizeF, float addScale, float powScale,
+                                  bool blocked);
+void ResponseNormCrossMap(cudamat* images, cudamat* targets, int numFilters, int sizeF,
+                          float addScale, float powScale, bool blocked);
+void ResponseNormCrossMapUndo(cudamat* outGrads, cudamat* inputs, cudamat* acts, cudamat* targets,
+                              int numFilters, int sizeF, float addScale, float powScale,
+                              bool blocked);
+
+/* ---- dense ops (cudamat.cuh:170-263) ------------------------------------------------------------- */
+/* target = beta*target + alpha*op(mat1)*op(mat2), op = transpose iff is_trans (cudamat.cu:2130-2152).
+ * fc_edge.cc's three uses (NT fwd, NN dgrad, TN wgrad) run on fp32 MFMA; TT is ERROR_UNSUPPORTED. */
+int dot(cudamat* mat1, cudamat* mat2, cudamat* target, float beta, float alpha);
+float vdot(cudamat* mat1, cudamat* mat2, int* err_code);
+int add_row_vec(cudamat* mat, cudamat* vec, cudamat* target);
+int add_row_mult(cudamat* mat, cudamat* vec, cudamat* target, float mult);
+int sum_by_axis(cudamat* mat, cudamat* target, int axis, float mult, float p);   /* target = p*target + mult*sum */
+int sqsum_by_axis(cudamat* mat, cudamat* target, int axis, float mult, float p);
+float sum_all(cudamat* mat, int* err_code);
+float euclid_norm(cudamat* mat, int* err_code);
+int normlimit_by_axis(cudamat* mat, cudamat* target, int axis, float norm, int constraint);
+int lower_bound_scalar(cudamat* mat, float val, cudamat* target);
+int upper_bound_mod_scalar(cudamat* mat, float val, cudamat* target);
+int apply_rectified_linear_deriv(cudamat* mat1, cudamat* mat2, cudamat* target);
+int assign_scalar(cudamat* mat, float alpha);
+int add_scalar(cudamat* mat, float alpha, cudamat* target);
+int mult_by_scalar(cudamat* mat, float alpha, cudamat* target, float scale_targets);
+int divide_by_scalar(cudamat* mat, float alpha, cudamat* target);
+int add_mult(cudamat* mat1, cudamat* mat2, float alpha);                         /* mat1 += alpha*mat2 */
+int add_elementwise(cudamat* mat1, cudamat* mat2, cudamat* target);
+int subtract_elementwise(cudamat* mat1, cudamat* mat2, cudamat* target);
+int mult_elementwise(cudamat* mat1, cudamat* mat2, cudamat* target, float scale_targets);
+int apply_sqrt(cudamat* mat, cudamat* target);
+
+/* ---- output layer (cudamat.cuh:249-262) ------------------------------------------------------------ */
+int softmax_row_major(cudamat* mat, cudamat* target);
+int softmax_row_major_multi(cudamat* mat, int numslices, cudamat* target);
+int apply_softmax_grad_row_major(cudamat* mat, cudamat* labels, cudamat* target);
+int get_softmax_correct_row_major(cudamat* mat, cudamat* labels, cudamat* target);
+int get_softmax_cross_entropy_row_major(cudamat* mat, cudamat* labels, cudamat* target, float tiny);
+
+/* ---- RNG (cudamat.cuh:117-119,154-164).  The reference's GPU (multiply-with-carry) and CPU
+ * (std::default_random_engine) streams already differ from each other; this
+ * library uses a counter-based Philox-4x32-10 keyed by (seed, call counter, element index). --------- */
+typedef struct rnd_struct {
+  unsigned int* dev_mults;          /* unused; layout kept (cudamat.cuh:50-53) */
+  unsigned long long* dev_words;    /* points at a host-side {seed, counter} pair owned by the library */
+} rnd_struct;
+int init_random(rnd_struct* rnd_state, int seed);
+int fill_with_rand(rnd_struct* rnd_state, cudamat* mat);
+int fill_with_randn(rnd_struct* rnd_state, cudamat* mat);
+int sample_bernoulli(rnd_struct* rnd_state, cudamat* mat, cudamat* target);
+int dropout(rnd_struct* rnd_state, cudamat* mat, float dropprob, float val, float scale);
+
+/* ---- fused entry points (new; SURVEY.md §7 "offer fused entry points in the ABI") ------------------
+ * Same arithmetic as the unfused sequences they replace, fewer passes over HBM.
+ *  convUpBiasAct      : convUpGemm + reshape/add_row_vec(shared bias) [+ lower_bound_scalar(0)]
+ *                        (src/conv_edge.cc:138-149 + src/layer.cc:549-551)
+ *  dotBiasAct         : dot(NT) + add_row_vec [+ ReLU]   (src/fc_edge.cc:51-61)
+ *  sgd_momentum_step  : SGDOptimizer::Optimize, non-Nesterov (src/optimizer.cc:174-200) in one pass
+ *                        (row-norm constraint excluded: call normlimit_by_axis after).
+ *  softmax_ce_grad_correct: softmax + SoftmaxCEDeriv + SoftmaxCorrect accumulation
+ *                        (src/layer.cc:570-572, src/loss_functions.cc:81-83,114-120); `correct_accum`
+ *                        is a 1x1 device matrix accumulated with atomics-free per-call add, so the
+ *                        host can read it every print_after steps instead of every step.
+ *  relu_dropout       : lower_bound_scalar(0) then dropout(p, 0, scale) (src/layer.cc:391,549). */
+void convUpBiasAct(cudamat* images, cudamat* filters, cudamat* bias, cudamat* targets,
+                   Shape4D* images_shape, Shape4D* filters_shape, Shape4D* targets_shape,
+                   ConvDesc conv_desc, float scaleTargets, int relu);
+int dotBiasAct(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target, float beta, float alpha,
+               int relu);
+int sgd_momentum_step(cudamat* grad, cudamat* param, cudamat* history, float l2_decay,
+                      float gradient_clip, float epsilon, float momentum);
+int softmax_ce_grad_correct(cudamat* logits, cudamat* labels, cudamat* probs, cudamat* deriv,
+                            cudamat* correct_accum, float deriv_scale);
+int relu_dropout(rnd_struct* rnd_state, cudamat* mat, float dropprob, float scale);
+
+/* ---- introspection for the roofline report: flops of the last MFMA launch family ----------------- */
+typedef struct ConvnetHipKernelInfo {
+  const char* name;      /* kernel family of the last conv/dot call */
+  double flops;          /* algorithmic flops of that call (2*M*N*K) */
+  int grid_blocks;
+  int split_k;
+} ConvnetHipKernelInfo;
+void convnet_hip_last_kernel_info(ConvnetHipKernelInfo* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* CONVNET_HIP_H_ */

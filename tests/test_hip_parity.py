@@ -1,0 +1,266 @@
+"""GPU parity tests proper: the HIP hot path, called through the C ABI (class Matrix -> ctypes ->
+libconvnet_hip.so), against (1) the committed golden outputs of the reference's own CPU code and
+(2) the CPU oracle on seeded inputs, using the reference's acceptance metric and tolerance:
+max|a-b| / mean|a+b| < 1e-4 (py/test_conv.py:382-392).  Selection ops must be bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402
+from oracle import Geom  # noqa: E402
+from golden_cases import compute_all, rel_err  # noqa: E402
+
+TOL = 1e-4   # the reference's own kernel-test tolerance (py/test_conv.py:387-392)
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hotpath_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from convnet_amd.matrix import Matrix
+    from hip_adapter import HipImpl
+    Matrix.SetupCUDADevice(0)
+    Matrix.InitRandom(42)
+    return HipImpl()
+
+
+def rnd(rng, shape):
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+def test_golden_vectors(hip):
+    golden = dict(np.load(GOLDEN))
+    got = compute_all(hip)
+    assert set(got) == set(golden)
+    for k in sorted(golden):
+        if k.endswith("/max") or k in ("softmax/grad", "softmax/correct"):
+            if k == "softmax/grad":
+                assert rel_err(got[k], golden[k]) < 1e-6, k
+            else:
+                assert np.array_equal(got[k], golden[k]), k
+        else:
+            assert rel_err(got[k], golden[k]) < TOL, (k, rel_err(got[k], golden[k]))
+
+
+def test_golden_sgd_fused_is_bit_exact(hip):
+    """The one-pass SGD kernel keeps every reference statement a separately rounded fp32 op."""
+    from hip_adapter import HipImpl
+    from golden_cases import inputs
+    golden = dict(np.load(GOLDEN))
+    g0, w0, h0 = inputs(403, (30, 12), (30, 12), (30, 12))
+    HipImpl(fused=True).sgd_step(g0, w0, h0, 5e-4, 0.9, 0.01, 0.7, 0.8, 0.0)
+    assert np.array_equal(g0, golden["sgd/grad"]) and np.array_equal(h0, golden["sgd/hist"])
+    assert rel_err(w0, golden["sgd/param"]) < 1e-6  # row-norm limit uses a different summation order
+
+
+CONV_CASES = [
+    # py/test_conv.py Test2D (:394-418)
+    Geom(N=128, C=32, H=12, W=12, F=64, Ky=3, Kx=3, sy=2, sx=2, pady=1, padx=1),
+    # ragged everything: N%4!=0, F%4!=0, rectangular image/kernel/stride
+    Geom(N=5, C=3, H=17, W=15, F=7, Ky=5, Kx=3, sy=2, sx=1, pady=2, padx=1),
+    Geom(N=100, C=1, H=28, W=28, F=48, Ky=4, Kx=4),                                    # mnist-conv conv1, bs=100
+    Geom(N=100, C=48, H=11, W=11, F=128, Ky=4, Kx=4),                                  # mnist-conv conv2
+    Geom(N=8, C=3, H=64, W=64, F=96, Ky=7, Kx=7, sy=2, sx=2, pady=1, padx=1),          # AlexNet conv1 (cropped image)
+    Geom(N=8, C=96, H=27, W=27, F=256, Ky=5, Kx=5, sy=2, sx=2),                         # AlexNet conv2 (cropped)
+    Geom(N=16, C=256, H=13, W=13, F=384, Ky=3, Kx=3, pady=1, padx=1),                  # AlexNet conv3 (exact)
+    Geom(N=132, C=16, H=7, W=7, F=40, Ky=3, Kx=3, pady=1, padx=1),                     # N just over one 128 block
+    Geom(N=4, C=8, H=9, W=9, F=200, Ky=3, Kx=3, sy=3, sx=3),                            # stride == kernel
+    Geom(N=4, C=8, H=10, W=10, F=33, Ky=2, Kx=2, sy=3, sx=3),                           # stride > kernel (uncovered pixels)
+]
+
+
+@pytest.mark.parametrize("g", CONV_CASES, ids=lambda g: f"N{g.N}C{g.C}H{g.H}F{g.F}k{g.Ky}s{g.sy}p{g.pady}")
+def test_conv_up_down_outp_vs_oracle(hip, g):
+    rng = np.random.default_rng(11)
+    x, w, dy = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape()), rnd(rng, g.out_shape())
+    for st in (0.0, 1.0):
+        t0 = rnd(rng, g.out_shape())
+        assert rel_err(hip.conv_up(g, x, w, t0.copy(), st), oracle.port.conv_up(g, x, w, t0.copy(), st)) < TOL
+        t0 = rnd(rng, g.in_shape())
+        assert rel_err(hip.conv_down(g, dy, w, t0.copy(), st), oracle.port.conv_down(g, dy, w, t0.copy(), st)) < TOL
+        t0 = rnd(rng, g.filt_shape())
+        so = 0.37 / g.N
+        assert rel_err(hip.conv_outp(g, x, dy, t0.copy(), st, so), oracle.port.conv_outp(g, x, dy, t0.copy(), st, so)) < TOL
+
+
+def test_conv_fused_bias_relu_equals_unfused_sequence(hip):
+    g = Geom(N=16, C=8, H=9, W=9, F=24, Ky=3, Kx=3, pady=1, padx=1)
+    rng = np.random.default_rng(12)
+    x, w, b = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape()), rnd(rng, (g.F,))
+    fused = hip.conv_up_bias_relu(g, x, w, b, relu=True)
+    y = oracle.port.conv_up(g, x, w)
+    y = oracle.port.add_row_vec(y.reshape(g.F, -1), b).reshape(g.out_shape())  # (N*My*Mx, F) + row vec: conv_edge.cc:146-148
+    y = oracle.port.lower_bound(y, 0.0)
+    assert rel_err(fused, y) < TOL
+
+
+POOL_CASES = [
+    Geom(N=128, C=32, H=12, W=12, F=32, Ky=3, Kx=3, sy=2, sx=2, pady=1, padx=1),
+    Geom(N=7, C=5, H=11, W=11, F=5, Ky=3, Kx=3, sy=2, sx=2, pady=1, padx=1),
+    Geom(N=100, C=48, H=25, W=25, F=48, Ky=4, Kx=4, sy=2, sx=2),                     # mnist-conv pool1
+    Geom(N=16, C=96, H=110, W=110, F=96, Ky=3, Kx=3, sy=2, sx=2, pady=1, padx=1),    # AlexNet pool1 (exact spatial)
+    Geom(N=6, C=3, H=9, W=7, F=3, Ky=3, Kx=2, sy=2, sx=1, pady=1, padx=0),           # rectangular
+]
+
+
+@pytest.mark.parametrize("g", POOL_CASES, ids=lambda g: f"N{g.N}C{g.C}H{g.H}k{g.Ky}s{g.sy}p{g.pady}")
+def test_pooling_vs_oracle(hip, g):
+    rng = np.random.default_rng(13)
+    x = np.maximum(rnd(rng, g.in_shape()), 0)   # post-ReLU input: exact ties at 0 everywhere
+    dy = rnd(rng, g.pooled_shape())
+    mp = hip.max_pool(g, x)
+    assert np.array_equal(mp, oracle.port.max_pool(g, x))
+    assert rel_err(hip.avg_pool(g, x), oracle.port.avg_pool(g, x)) < 1e-6
+    for st in (0.0, 1.0):
+        t0 = rnd(rng, g.in_shape())
+        assert rel_err(hip.max_pool_undo(g, x, dy, mp, t0.copy(), st), oracle.port.max_pool_undo(g, x, dy, mp, t0.copy(), st)) < 1e-6
+        assert rel_err(hip.avg_pool_undo(g, dy, t0.copy(), st), oracle.port.avg_pool_undo(g, dy, t0.copy(), st)) < 1e-6
+
+
+def test_max_pool_undo_routes_gradient_to_every_tie(hip):
+    """an argmax-index implementation is NOT parity-equivalent."""
+    g = Geom(N=4, C=1, H=4, W=4, F=1, Ky=2, Kx=2, sy=2, sx=2)
+    x = np.zeros(g.in_shape(), np.float32)          # every window is a 4-way tie
+    dy = np.ones(g.pooled_shape(), np.float32)
+    mp = hip.max_pool(g, x)
+    out = hip.max_pool_undo(g, x, dy, mp)
+    assert np.array_equal(out, np.ones(g.in_shape(), np.float32))
+
+
+@pytest.mark.parametrize("shape,size_f,blocked", [
+    ((32, 6, 6, 128), 8, False),        # Test2D rnorm: sizeF=8, add .005, pow .75
+    ((96, 5, 5, 16), 24, False),        # AlexNet rnorm1 channel geometry
+    ((256, 3, 3, 8), 64, False),        # AlexNet rnorm2
+    ((20, 2, 3, 5), 5, True),
+    ((7, 2, 2, 3), 3, False),           # ragged location count
+])
+def test_response_norm_vs_oracle(hip, shape, size_f, blocked):
+    rng = np.random.default_rng(14)
+    x, dy = rnd(rng, shape), rnd(rng, shape)
+    assert rel_err(hip.rnorm(x, size_f, 0.005, 0.75, blocked), oracle.port.rnorm(x, size_f, 0.005, 0.75, blocked)) < TOL
+    assert rel_err(hip.rnorm_undo(dy, x, size_f, 0.005, 0.75, blocked), oracle.port.rnorm_undo(dy, x, size_f, 0.005, 0.75, blocked)) < TOL
+
+
+@pytest.mark.parametrize("N,D,F", [(256, 1152, 1000), (100, 1152, 10), (9, 37, 11), (128, 4096, 512), (32, 260, 132)])
+def test_fc_dot_three_forms_vs_oracle(hip, N, D, F):
+    rng = np.random.default_rng(15)
+    x, w, dy = rnd(rng, (D, N)), rnd(rng, (D, F)) * 0.1, rnd(rng, (F, N))
+    for beta in (0.0, 1.0):
+        t0 = rnd(rng, (F, N))   # fc_edge.cc:54  out = in * W^T
+        assert rel_err(hip.dot(x, w, t0.copy(), beta, 1.0, False, True), oracle.port.dot(x, w, t0.copy(), beta, 1.0, False, True)) < TOL
+        t0 = rnd(rng, (D, N))   # fc_edge.cc:66  d_in = d_out * W
+        assert rel_err(hip.dot(dy, w, t0.copy(), beta, 1.0), oracle.port.dot(dy, w, t0.copy(), beta, 1.0)) < TOL
+        t0 = rnd(rng, (D, F))   # fc_edge.cc:74  dW = d_out^T * in / N
+        assert rel_err(hip.dot(dy, x, t0.copy(), beta, 1.0 / N, True, False), oracle.port.dot(dy, x, t0.copy(), beta, 1.0 / N, True, False)) < TOL
+
+
+def test_linearity_and_adjointness_at_full_alexnet_conv3_size(hip):
+    """Size-independent properties at BASELINE's full layer size (N=256), where the CPU oracle would
+    take minutes: <conv(x,w), dy> == <x, convT(dy,w)> == <w, wgrad(x,dy)> (the three kernels are
+    mutually adjoint), checked in float64 on the host."""
+    g = Geom(N=256, C=256, H=13, W=13, F=384, Ky=3, Kx=3, pady=1, padx=1)
+    rng = np.random.default_rng(16)
+    x, w, dy = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape()) * 0.05, rnd(rng, g.out_shape())
+    y = hip.conv_up(g, x, w)
+    dx = hip.conv_down(g, dy, w)
+    dw = hip.conv_outp(g, x, dy)
+    a = float(np.vdot(y.astype(np.float64), dy.astype(np.float64)))
+    b = float(np.vdot(x.astype(np.float64), dx.astype(np.float64)))
+    c = float(np.vdot(w.astype(np.float64), dw.astype(np.float64)))
+    assert abs(a - b) / abs(a) < 1e-5 and abs(a - c) / abs(a) < 1e-5, (a, b, c)
+    # spot-check 64 output elements exactly against a float64 dot product of the gathered patch
+    for _ in range(64):
+        n, f, oy, ox = rng.integers(g.N), rng.integers(g.F), rng.integers(g.My), rng.integers(g.Mx)
+        acc = 0.0
+        for ky in range(g.Ky):
+            for kx in range(g.Kx):
+                iy, ix = oy + ky - 1, ox + kx - 1
+                if 0 <= iy < g.H and 0 <= ix < g.W:
+                    acc += float(np.dot(x[:, iy, ix, n].astype(np.float64), w[:, ky, kx, f].astype(np.float64)))
+        assert abs(acc - y[f, oy, ox, n]) < 1e-4 * max(1.0, abs(acc))
+
+
+def test_softmax_family_and_fused(hip):
+    from convnet_amd.matrix import Matrix
+    from hip_adapter import _mat
+    rng = np.random.default_rng(17)
+    N, K = 256, 1000
+    z = (3 * rnd(rng, (K, N)))
+    labels = rng.integers(0, K, N).astype(np.float32)
+    p_ref = oracle.port.softmax_row_major(z.copy())
+    assert rel_err(hip.softmax_row_major(z.copy()), p_ref) < 1e-5
+    assert np.array_equal(hip.softmax_correct_row_major(p_ref, labels), oracle.port.softmax_correct_row_major(p_ref, labels))
+    assert rel_err(hip.softmax_ce_row_major(p_ref, labels), oracle.port.softmax_ce_row_major(p_ref, labels)) < 1e-5
+    assert np.array_equal(hip.softmax_grad_row_major(p_ref, labels), oracle.port.softmax_grad_row_major(p_ref, labels))
+    # fused: softmax + CE-deriv + correct count
+    Z, L = _mat(z, N, K), _mat(labels, N, 1)
+    P, D, C = _mat(np.zeros_like(z), N, K), _mat(np.zeros_like(z), N, K), _mat(np.zeros(1, np.float32), 1, 1)
+    Matrix.SoftmaxCEGradCorrect(Z, L, P, D, C)
+    assert rel_err(P.ToNumpy().reshape(z.shape), p_ref) < 1e-5
+    assert rel_err(D.ToNumpy().reshape(z.shape), oracle.port.softmax_grad_row_major(p_ref, labels)) < 1e-5
+    assert C.ToNumpy().reshape(-1)[0] == oracle.port.softmax_correct_row_major(p_ref, labels).sum()
+
+
+def test_elementwise_reductions_and_views(hip):
+    from convnet_amd.matrix import Matrix
+    from hip_adapter import _mat
+    rng = np.random.default_rng(18)
+    a = rnd(rng, (37, 50))   # (rows=50, cols=37)
+    b = rnd(rng, (37,))
+    assert rel_err(hip.add_row_vec(a.copy(), b), oracle.port.add_row_vec(a.copy(), b)) < 1e-7
+    for axis, n in ((0, 37), (1, 50)):
+        t0 = rnd(rng, (n,))
+        assert rel_err(hip.sum_by_axis(a, t0.copy(), axis, 0.5, 1.0), oracle.port.sum_by_axis(a, t0.copy(), axis, 0.5, 1.0)) < 1e-5
+    big = rnd(rng, (3, 5000))   # long columns: block-per-column path
+    t0 = np.zeros(3, np.float32)
+    assert rel_err(hip.sum_by_axis(big, t0.copy(), 0, 1.0, 0.0), oracle.port.sum_by_axis(big, t0.copy(), 0, 1.0, 0.0)) < 1e-5
+    assert np.array_equal(hip.lower_bound(a.copy(), 0.0), oracle.port.lower_bound(a.copy(), 0.0))
+    assert np.array_equal(hip.upper_bound_mod(a.copy(), 0.4), oracle.port.upper_bound_mod(a.copy(), 0.4))
+    st = np.maximum(rnd(rng, a.shape), 0)
+    assert np.array_equal(hip.relu_deriv(a.copy(), st), oracle.port.relu_deriv(a.copy(), st))
+    for lim, con in ((0.8, False), (1.5, True)):
+        assert rel_err(hip.normlimit_rows(a.copy(), lim, con), oracle.port.normlimit_rows(a.copy(), lim, con)) < 1e-6
+    # views: slice + reshape share memory (cudamat.cu:587-626)
+    M = _mat(a, 50, 37)
+    S = Matrix()
+    M.GetSlice(S, 5, 9)
+    S.Set(7.0)
+    back = M.ToNumpy()
+    assert np.all(back[5:9] == 7.0) and np.array_equal(back[:5], a[:5]) and np.array_equal(back[9:], a[9:])
+    assert abs(M.Sum() - float(back.astype(np.float64).sum())) < 1e-2
+    assert M.ReadValue(3, 2) == back[2, 3]
+    M.WriteValue(3, 2, -1.5)
+    assert M.ReadValue(3 + 50 * 2) == -1.5
+
+
+def test_dropout_statistics_and_relu_dropout(hip):
+    from convnet_amd.matrix import Matrix
+    from hip_adapter import _mat
+    n = 1 << 20
+    x = np.random.default_rng(19).standard_normal(n).astype(np.float32)
+    M = _mat(x, n, 1)
+    M.Dropout(0.4, 0.0, 1.0 / 0.6)
+    y = M.ToNumpy().reshape(-1)
+    dropped = (y == 0)
+    assert abs(dropped.mean() - 0.4) < 5e-3
+    assert np.allclose(y[~dropped], x[~dropped] * np.float32(1.0 / 0.6), rtol=1e-6)
+    M2 = _mat(x, n, 1)
+    M2.ReluDropout(0.4, 1.0 / 0.6)
+    y2 = M2.ToNumpy().reshape(-1)
+    kept = y2 != 0
+    assert np.all(x[kept] > 0) and np.allclose(y2[kept], x[kept] * np.float32(1.0 / 0.6), rtol=1e-6)
+    pos = x > 0
+    assert abs((y2[pos] == 0).mean() - 0.4) < 5e-3
+    R = Matrix()
+    R.AllocateGPUMemory(n, 1)
+    R.FillWithRandn()
+    r = R.ToNumpy().reshape(-1)
+    assert abs(r.mean()) < 5e-3 and abs(r.std() - 1) < 5e-3
+    R.FillWithRand()
+    r = R.ToNumpy().reshape(-1)
+    assert r.min() >= 0 and r.max() < 1 and abs(r.mean() - 0.5) < 2e-3
