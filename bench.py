@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of one full training step (fprop + bprop + wgrad + SGD [+ gradient
+exchange]) of the AlexNet-class model (BASELINE.json metric) on N MI355X GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  Each rank trains a full replica on its own synthetic batch of --batch images
+(weak scaling, exactly the reference's train_convnet_data_parallel semantics: every MPI rank reads
+its own batch of `batch_size` and the gradients are averaged, src/convnet.cc:407-450).  Rank 0 prints
+ONE JSON line.  `value` = images processed by all ranks / max-over-ranks wall time of K steps,
+bracketed by barrier + torch.cuda.synchronize().
+
+Extra objects on the line:
+  roofline      dominant MFMA kernel: algorithmic flops / HIP-event time measured per launch inside
+                the timed region, against the fp32-matrix peak (157.3 TFLOP/s; the parity path is
+                fp32 because grad_check needs it).  Also `model_frac` = whole-step algorithmic
+                flops / step time / peak, and per-kernel-family rows under `families`.
+  cpu_baseline  the reference's own CPU path (oracle/_ref, eigenmat+CPUMatrix compiled unmodified)
+                — or the C port if that build is absent — running the same model's training step
+                on a bounded sample (N=2 images, 1 step), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD @ 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(sample_n=2):
+    """Time the reference CPU path on the AlexNet-class training step at a reduced batch.
+    Test infrastructure used strictly as a *baseline*, never as the thing measured above."""
+    import numpy as np
+    import oracle
+    from oracle import Geom
+    impl = oracle.ref if oracle.ref is not None else oracle.port
+    N = sample_n
+    rng = np.random.default_rng(0)
+
+    def rnd(*s):
+        return rng.standard_normal(s).astype(np.float32)
+
+    convs = [Geom(N, 3, 224, 224, 96, 7, 7, 2, 2, 1, 1), Geom(N, 96, 55, 55, 256, 5, 5, 2, 2, 0, 0),
+             Geom(N, 256, 13, 13, 384, 3, 3, 1, 1, 1, 1), Geom(N, 384, 13, 13, 384, 3, 3, 1, 1, 1, 1),
+             Geom(N, 384, 13, 13, 256, 3, 3, 1, 1, 0, 0)]
+    pools = {0: Geom(N, 96, 110, 110, 96, 3, 3, 2, 2, 1, 1), 1: Geom(N, 256, 26, 26, 256, 3, 3, 2, 2, 1, 1),
+             4: Geom(N, 256, 11, 11, 256, 3, 3, 2, 2, 1, 1)}
+    rn = {0: 24, 1: 64}
+    fcs = [(9216, 4096), (4096, 4096), (4096, 1000)]
+    W = [rnd(*g.filt_shape()) * 0.01 for g in convs]
+    Wf = [rnd(d, f) * 0.01 for d, f in fcs]
+    x = rnd(*convs[0].in_shape())
+    t0 = time.perf_counter()
+    acts, cache = [x], []
+    h = x
+    for i, g in enumerate(convs):   # forward
+        y = impl.lower_bound(impl.conv_up(g, h, W[i]), 0.0)
+        rec = {"in": h, "y": y}
+        h = y
+        if i in pools:
+            p = impl.max_pool(pools[i], h)
+            rec["pool_in"], rec["pool_out"] = h, p
+            h = p
+        if i in rn:
+            r = impl.rnorm(h, rn[i], 0.0005, 0.75)
+            rec["rn_in"] = h
+            h = r
+        cache.append(rec)
+    h = np.ascontiguousarray(h.reshape(-1, N))
+    fc_in = []
+    for (d, f), w in zip(fcs, Wf):
+        fc_in.append(h)
+        h = impl.dot(h, w, np.zeros((f, N), np.float32), 0.0, 1.0, False, True)
+        if f != 1000:
+            h = impl.lower_bound(h, 0.0)
+    p = impl.softmax_row_major(h)
+    dy = impl.softmax_grad_row_major(p, np.zeros(N, np.float32))
+    for (d, f), w, hin in reversed(list(zip(fcs, Wf, fc_in))):   # backward
+        impl.dot(dy, hin, np.zeros((d, f), np.float32), 0.0, 1.0 / N, True, False)
+        dy = impl.dot(dy, w, np.zeros((d, N), np.float32), 0.0, 1.0)
+    dy = np.ascontiguousarray(dy.reshape(convs[4].C if False else 256, 6, 6, N))
+    for i in reversed(range(len(convs))):
+        g, rec = convs[i], cache[i]
+        if i in rn:
+            dy = impl.rnorm_undo(dy, rec["rn_in"], rn[i], 0.0005, 0.75)
+        if i in pools:
+            dy = impl.max_pool_undo(pools[i], rec["pool_in"], dy, rec["pool_out"])
+        dy = impl.relu_deriv(dy, rec["y"])
+        impl.conv_outp(g, rec["in"], dy, None, 0.0, 1.0 / N)
+        if i > 0:
+            dy = impl.conv_down(g, dy, W[i])
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": round(N / dt, 4), "unit": "images/sec", "cores": cores, "kind": impl.kind,
+            "sample": f"AlexNet-class training step (conv/fc fprop+dgrad+wgrad, max-pool, response-norm, softmax) at N={N}, 1 step, "
+                      f"{dt:.1f}s; the reference's conv is a single-threaded naive sgemm per output location "
+                      f"(eigenmat.cc:2284-2298), only its pooling/softmax loops use OpenMP"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--model", default="alexnet", choices=["alexnet", "mnist_conv", "lenet5", "vgg"])
+    ap.add_argument("--unfused", action="store_true", help="issue the reference's unfused Matrix-call sequence")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=8.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from convnet_amd import _lib, models
+    from convnet_amd.convnet import ConvNet
+    from convnet_amd.datahandler import SyntheticDataHandler
+    from convnet_amd.matrix import Matrix
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
+    Matrix.SetupCUDADevice(local_rank)
+    exchange = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        from convnet_amd.data_parallel import GradientExchange
+        exchange = GradientExchange(bucket_bytes=int(args.bucket_mb * (1 << 20)), overlap=not args.no_overlap)
+
+    text = getattr(models, args.model)()
+    net = ConvNet(text, fused=not args.unfused, process_id=rank, num_processes=world, exchange=exchange)
+    net.SetBatchsize(args.batch)
+    data = SyntheticDataHandler(net, args.batch, seed=1000 + rank, num_batches=2)
+    net.SetupDataset(data)
+    net.AllocateMemory(False)
+    fwd_macs, train_macs = models.count_macs(net)
+    step_flops = 2.0 * train_macs * args.batch
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        net.TrainOneBatch()
+    sync_all()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net.TrainOneBatch()
+    sync_all()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    prof = _lib.profile_report()
+
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        images = args.batch * world * args.steps
+        value = images / dt
+        ms_per_step = 1e3 * dt / args.steps
+        fam = {}
+        for r in prof:
+            f = fam.setdefault(r["kernel"], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            for k in ("launches", "ms", "flops", "bytes"):
+                f[k] += r[k]
+        mfma = {k: v for k, v in fam.items() if v["flops"] > 0}
+        roofline = None
+        if mfma:
+            dom_name, dom = max(mfma.items(), key=lambda kv: kv[1]["ms"])
+            achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            all_flops = sum(v["flops"] for v in mfma.values())
+            all_ms = sum(v["ms"] for v in mfma.values())
+            roofline = {
+                "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                "flops_per_launch": dom["flops"] / dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                "launches": dom["launches"],
+                "all_mfma_kernels": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
+                                     "frac": round(all_flops / (all_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+                                     "ms_per_step": round(all_ms / args.steps, 3)},
+                "model_frac": round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+                "families": {k: {"launches_per_step": v["launches"] / args.steps, "ms_per_step": round(v["ms"] / args.steps, 4),
+                                 **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] > 0 else
+                                    {"gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)})}
+                             for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
+                "ops": {f'{r["kernel"]}|{r["op"]}': round(r["ms"] / args.steps, 4) for r in sorted(prof, key=lambda r: -r["ms"])},
+            }
+        out = {
+            "metric": "images/sec (fprop+bprop+wgrad) AlexNet 224x224 bs=256" if args.model == "alexnet" else f"images/sec {args.model}",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} (convnet_amd.models.{args.model}: the reference's AlexNet-class ILSVRC pbtxt) "
+                                   f"training step, 224x224x3 synthetic N(0,1) images, {args.batch} images per GPU, "
+                                   f"SGD+momentum+L2, dropout on, {'fused' if not args.unfused else 'unfused'} ABI calls",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}" + ("" if world == 1 else (" rccl-allreduce " + ("overlapped" if not args.no_overlap else "serial"))),
+                       "params": net.NumParameters(), "train_gflop_per_image": round(2e-9 * train_macs, 4)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+                out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

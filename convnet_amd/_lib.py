@@ -83,6 +83,8 @@ def _load():
     sig("cuda_set_device", I, I)
     sig("cuda_sync_threads", None)
     sig("convnet_hip_last_kernel_info", None, P(KernelInfo))
+    sig("convnet_hip_profile_enable", None, I)
+    sig("convnet_hip_profile_report", ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t)
     for n in ("allocate_device_memory", "free_device_memory", "copy_to_host", "copy_to_device"):
         sig(n, I, M)
     sig("copy_to_host_slice", I, M, ctypes.c_size_t, ctypes.c_size_t)
@@ -157,6 +159,21 @@ _ERRORS = {  # reference src/util.cc:226-246 GetStringError
     -1: "Incompatible matrix dimensions.", -2: "CUBLAS error.", -3: "CUDA error: ", -4: "Operation not supported on views.",
     -5: "Operation not supported on transposed matrices.", -6: "Generic error.",
     -7: "Incompatible transposedness.", -8: "Matrix is not in device memory.", -9: "Operation not supported."}
+
+
+def profile_enable(on=True):
+    lib.convnet_hip_profile_enable(1 if on else 0)
+
+
+def profile_report():
+    """[{kernel, op, launches, ms, flops, bytes}] for launches since the last report."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    n = lib.convnet_hip_profile_report(buf, len(buf))
+    rows = []
+    for line in buf.value.decode().splitlines() if n else []:
+        k, op, cnt, ms, fl, by = line.split("|")
+        rows.append({"kernel": k, "op": op, "launches": int(cnt), "ms": float(ms), "flops": float(fl), "bytes": float(by)})
+    return rows
 
 
 def GetStringError(err_code):

@@ -1,0 +1,301 @@
+"""ConvNet — mirror of src/convnet.{h,cc} for the training hot path: build the graph from a pbtxt
+model, topologically sort, allocate the flat parameter / gradient buffers, Fprop / Bprop /
+UpdateWeights / TrainOneBatch.
+
+What changed relative to the reference, and why (MI355X-first):
+  * Gradient exchange.  The reference D2H-copies the whole 249 MB gradient, sums it on rank 0 through
+    MPI_Send/Recv, divides, and MPI_Bcasts it back (src/convnet.cc:407-450) *after* Bprop returns.
+    Here every edge's gradient slice is all-reduced by RCCL (torch.distributed "nccl" backend over
+    xGMI) on a communication stream the moment ComputeOuter has produced it, overlapping the rest
+    of the backward pass; UpdateWeights waits per slice right before its optimizer step
+    (data_parallel.GradientExchange).
+  * GetLoss no longer forces a device->host sync every step (src/convnet.cc:482 -> matrix.cc:253-268):
+    with ``fused=True`` the correct-count accumulates on device and is read every ``print_after``.
+  * ``fused=True`` routes conv+bias+ReLU, FC+bias+ReLU, ReLU+dropout, softmax+CE-deriv+count and
+    the SGD step through the library's fused entry points.  ``fused=False`` issues exactly the
+    reference's Matrix-call sequence (used by the parity tests and grad_check).
+"""
+import sys
+from collections import deque
+
+from . import pbtxt
+from .edge import ConvEdge, Edge, EdgeWithWeight, FCEdge
+from .layer import Layer, SoftmaxLayer
+from .matrix import Matrix
+
+
+class ConvNet:
+    def __init__(self, model, fused=False, process_id=0, num_processes=1, verbose=False, exchange=None):
+        """``model``: path to a pbtxt file, pbtxt text, or a parsed pbtxt.Model."""
+        self.verbose = verbose
+        self.fused = fused
+        self.process_id_ = process_id
+        self.num_processes_ = num_processes
+        self.is_root_ = process_id == 0
+        self.exchange_ = exchange
+        if isinstance(model, pbtxt.Model):
+            self.model_ = model
+        elif "\n" in model or "{" in model:
+            self.model_ = pbtxt.parse(model)
+        else:
+            self.model_ = pbtxt.read(model)
+        m = self.model_
+        # default optimizers for weights/biases whose optimizer is not specified (src/convnet.cc:36-50)
+        for e in m.edge:
+            if Edge.HasParameters(e):
+                w_opt = m.default_weight_optimizer.copy()
+                w_opt.MergeFrom(e.weight_optimizer)
+                e.mutable("weight_optimizer").CopyFrom(w_opt)
+                if not e.has_no_bias:
+                    b_opt = m.default_bias_optimizer.copy()
+                    b_opt.MergeFrom(e.bias_optimizer)
+                    e.mutable("bias_optimizer").CopyFrom(b_opt)
+        Matrix.InitRandom(m.seed + process_id)   # src/convnet.cc:67
+        self.model_name_ = m.name
+        self.layers_, self.edges_ = [], []
+        self.input_layers_, self.output_layers_, self.data_layers_ = [], [], []
+        self.batch_size_ = 0
+        self.current_iter_ = 0
+        self.parameters_, self.grad_parameters_, self.history_ = Matrix(), Matrix(), Matrix()
+        self.edge_slices_ = {}   # edge -> (offset, length) in the flat buffers
+        self.train_dataset_ = None
+        self.correct_accum_ = None
+        self.BuildNet()
+
+    def log(self, *a):
+        if self.verbose:
+            print(*a, file=sys.stderr)
+
+    # ---- graph: src/convnet.cc:150-242 ---------------------------------------------------------------
+    def BuildNet(self):
+        m = self.model_
+        self.layers_ = [Layer.ChooseLayerClass(l) for l in m.layer]
+        self.edges_ = [Edge.ChooseEdgeClass(e) for e in m.edge]
+        for e in self.edges_:
+            e.fused = self.fused
+            if isinstance(e, EdgeWithWeight):
+                e.weight_optimizer_.fused = self.fused
+                if e.bias_optimizer_ is not None:
+                    e.bias_optimizer_.fused = self.fused
+        by_name = {e.GetName(): e for e in self.edges_}
+        for e in self.edges_:
+            if e.IsTied():
+                e.SetTiedTo(by_name[e.GetTiedEdgeName()])
+        for l in self.layers_:
+            for e in self.edges_:
+                if l.GetName() == e.GetSourceName():
+                    l.AddOutgoing(e)
+                    e.SetSource(l)
+                    e.SetInputChannels(l.GetNumChannels())
+                if l.GetName() == e.GetDestName():
+                    l.AddIncoming(e)
+                    e.SetDest(l)
+                    e.SetOutputChannels(l.GetNumChannels())
+        self.Sort()
+        for l in self.layers_:
+            if not l.incoming_edge_:
+                self.input_layers_.append(l)
+                self.data_layers_.append(l)
+            if not l.outgoing_edge_:
+                self.output_layers_.append(l)
+                self.data_layers_.append(l)
+        for l in self.layers_:
+            if l.IsInput():
+                y, x, t = l.GetSizeY(), l.GetSizeX(), l.GetSizeT()
+                if y <= 0:
+                    y = m.patch_size
+                if x <= 0:
+                    x = m.patch_size
+                if t <= 0:
+                    t = 1
+            else:
+                e0 = l.incoming_edge_[0]
+                y, x, t = e0.GetNumModulesY(), e0.GetNumModulesX(), e0.GetNumModulesT()
+            l.SetSize(y, x, t)
+            self.log(f"Layer {l.GetName()}: {y}x{x}")
+            for e in l.outgoing_edge_:
+                e.SetImageSize(y, x, t)
+
+    def Sort(self):
+        # breadth-first topological sort, src/convnet.cc:312-353
+        L, S = [], deque(l for l in self.layers_ if l.IsInput())
+        if not S:
+            raise SystemExit("Error: No layer is set to be input!")
+        while S:
+            n = S.popleft()
+            L.append(n)
+            for e in n.outgoing_edge_:
+                e.SetMark()
+                mm = e.GetDest()
+                if mm is None:
+                    raise SystemExit(f"Edge {e.GetName()} has no destination layer")
+                if all(f.HasMark() for f in mm.incoming_edge_):
+                    S.append(mm)
+        if not all(f.HasMark() for f in self.edges_):
+            raise SystemExit("Error : Network has loop(s)!")
+        self.layers_ = L
+
+    def GetLayerByName(self, name):
+        for l in self.layers_:
+            if l.GetName() == name:
+                return l
+        raise SystemExit(f"Error: No layer called {name}")
+
+    def GetEdgeByName(self, name):
+        for e in self.edges_:
+            if e.GetName() == name:
+                return e
+        raise SystemExit(f"Error: No edge called {name}")
+
+    # ---- memory: src/convnet.cc:266-310 -----------------------------------------------------------------
+    def SetBatchsize(self, batch_size):
+        self.batch_size_ = batch_size
+
+    def AllocateMemory(self, fprop_only=False):
+        self.AllocateLayerMemory()
+        self.AllocateEdgeMemory(fprop_only)
+        if self.fused:
+            self.correct_accum_ = Matrix()
+            self.correct_accum_.AllocateGPUMemory(1, 1, "correct count")
+            self.correct_accum_.Set(0.0)
+
+    def AllocateLayerMemory(self):
+        for l in self.layers_:
+            l.AllocateMemory(self.batch_size_)
+
+    def AllocateEdgeMemory(self, fprop_only):
+        total, usage = 0, {}
+        for e in self.edges_:
+            mem = e.GetParameterMemoryRequirement()
+            usage[e] = mem
+            total += ((mem + 127) // 128) * 128   # 128-float aligned slices (src/convnet.cc:279)
+        self.parameters_.AllocateGPUMemory(1, total, "parameters")
+        if not fprop_only:
+            self.grad_parameters_.AllocateGPUMemory(1, total, "grad parameters")
+            self.grad_parameters_.Set(0.0)
+            self.history_.AllocateGPUMemory(1, total, "optimizer history")   # flat, same layout
+        offset = 0
+        for e in self.edges_:
+            mem = usage[e]
+            if mem == 0:
+                continue
+            s = Matrix()
+            self.parameters_.GetSlice(s, offset, offset + mem)
+            e.SetMemory(s)
+            if not fprop_only:
+                g, h = Matrix(), Matrix()
+                self.grad_parameters_.GetSlice(g, offset, offset + mem)
+                self.history_.GetSlice(h, offset, offset + mem)
+                e.SetGradMemory(g, h)
+            self.edge_slices_[e] = (offset, mem)
+            offset += ((mem + 127) // 128) * 128
+        if self.is_root_ or self.exchange_ is None:
+            for e in self.edges_:
+                e.Initialize()
+        if self.num_processes_ > 1 and self.exchange_ is not None:
+            self.exchange_.Broadcast(self.parameters_)   # src/convnet.cc:309
+            if not fprop_only:
+                self.exchange_.Register(self)
+
+    def NumParameters(self):
+        return sum(n for _, n in self.edge_slices_.values())
+
+    # ---- fprop / bprop: src/convnet.cc:355-405 ---------------------------------------------------------
+    def _can_fuse_up(self, l):
+        if not self.fused or len(l.incoming_edge_) != 1 or isinstance(l, SoftmaxLayer):
+            return False
+        e = l.incoming_edge_[0]
+        if isinstance(e, ConvEdge):
+            return e.has_no_bias_ or e.shared_bias_
+        return isinstance(e, FCEdge)
+
+    def Fprop(self, train):
+        for l in self.layers_:
+            fused_act = self._can_fuse_up(l)
+            for e in l.incoming_edge_:
+                src = e.GetSource()
+                overwrite = l.AddOrOverwriteState(e.GetDestSliceName())
+                e.ComputeUp(src.GetState(), l.GetState(), overwrite, train, fuse_relu=(l.is_relu if fused_act else None))
+            if not l.IsInput() and not fused_act:
+                if self.fused and isinstance(l, SoftmaxLayer) and l.IsOutput() and train:
+                    pass   # softmax + CE derivative + correct count are fused in ComputeDeriv
+                else:
+                    l.ApplyActivation()
+            l.ApplyDropout(train)
+
+    def _bprop_edge(self, output, input, edge):
+        # ConvNet::Bprop(output, input, edge), src/convnet.cc:362-375
+        if edge.IsBackPropBlocked():
+            return
+        edge.ComputeOuter(input.GetState(), output.GetDeriv())
+        if self.exchange_ is not None and edge in self.edge_slices_:
+            self.exchange_.GradReady(edge)      # wgrad of this edge is final: start its all-reduce
+        if not input.IsInput():
+            overwrite = input.AddOrOverwriteDeriv(edge.GetSourceSliceName())
+            edge.ComputeDown(output.GetDeriv(), input.GetState(), output.GetState(), input.GetDeriv(), overwrite)
+
+    def Bprop(self):
+        for l in reversed(self.layers_):
+            for e in l.outgoing_edge_:
+                self._bprop_edge(e.GetDest(), l, e)
+            l.ApplyDerivativeofDropout()
+            if not l.IsInput() and not l.IsOutput():
+                l.ApplyDerivativeOfActivation()
+
+    def ComputeDeriv(self):
+        for l in self.output_layers_:
+            if self.fused and isinstance(l, SoftmaxLayer):
+                Matrix.SoftmaxCEGradCorrect(l.GetState(), l.GetData(), l.GetState(), l.GetDeriv(), self.correct_accum_,
+                                            l.loss_function_weight_)
+            else:
+                l.ComputeDeriv()
+
+    def GetLoss(self):
+        """Per-output-layer performance metric (src/convnet.cc:456-461).  In fused mode the count
+        accumulates on device (no per-step sync) and GetLoss returns None."""
+        if self.fused:
+            return None
+        return [l.GetPerformanceMetric() for l in self.output_layers_]
+
+    def ReadCorrectCount(self, reset=True):
+        """Fused mode: number of correct predictions since the last read (one D2H sync)."""
+        v = float(self.correct_accum_.ToNumpy().reshape(-1)[0])
+        if reset:
+            self.correct_accum_.Set(0.0)
+        return v
+
+    # ---- update: src/convnet.cc:440-450 -------------------------------------------------------------------
+    def UpdateWeights(self):
+        for e in self.edges_:
+            if e.IsBackPropBlocked():
+                continue
+            if self.exchange_ is not None and e in self.edge_slices_:
+                self.exchange_.WaitFor(e)       # the averaged gradient slice has arrived
+            e.UpdateWeights()
+
+    # ---- data -------------------------------------------------------------------------------------------
+    def SetupDataset(self, dataset):
+        self.train_dataset_ = dataset
+        self.batch_size_ = dataset.GetBatchSize()
+
+    def GetBatch(self, dataset):
+        dataset.GetBatch(self.data_layers_)
+
+    def TrainOneBatch(self):
+        # src/convnet.cc:475-485
+        for l in self.layers_:
+            l.ResetAddOrOverwrite()
+        for e in self.edges_:
+            e.NotifyStart()
+        for l in self.layers_:
+            l.NotifyStart()
+        if self.exchange_ is not None:
+            self.exchange_.StartStep()
+        self.GetBatch(self.train_dataset_)
+        self.Fprop(True)
+        self.ComputeDeriv()
+        error = self.GetLoss()
+        self.Bprop()
+        self.UpdateWeights()
+        self.current_iter_ += 1
+        return error

@@ -18,6 +18,14 @@ void* workspace(size_t bytes);
 void set_last_error(const char* msg);
 void note_kernel(const char* name, double flops, int blocks, int split_k);
 
+// Optional per-launch timing with HIP events on the library stream (bench.py's roofline leg).
+// Off by default: when off, KernelTimer is two predictable branches.
+struct KernelTimer {
+  KernelTimer(const char* name, const char* op, double flops, double bytes);
+  ~KernelTimer();
+  int slot;
+};
+
 [[noreturn]] inline void fatal(const char* what, const char* file, int line) {
   // Same policy as the reference's conv back-end: shape/HIP errors are unrecoverable
   // (cudamat_conv_gemm.cu:35-42 getLastCudaError -> exit(EXIT_FAILURE)).

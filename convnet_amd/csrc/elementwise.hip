@@ -381,11 +381,18 @@ int rng_launch(rnd_struct* st, float* out, const float* in, size_t n, float p, f
 // statement a separately rounded fp32 op (no fma contraction), so the update is bit-identical
 // to the reference's multi-pass sequence.
 __device__ __forceinline__ void sgd_one(float& g, float& w, float& h, float l2, float clip, float eps, float mom) {
-  if (l2 > 0.f) g = __fadd_rn(g, __fmul_rn(w, l2));
+  // hipcc defaults to -ffp-contract=fast, and __fmul_rn/__fadd_rn are header functions compiled
+  // under that default (they still fuse).  Plain operators under contract(off) do not.
+#pragma clang fp contract(off)
+  if (l2 > 0.f) {
+    const float t = w * l2;
+    g = g + t;
+  }
   if (clip > 0.f) g = g > clip ? clip : (g < -clip ? -clip : g);
-  g = __fmul_rn(g, eps);
-  h = __fadd_rn(__fmul_rn(h, mom), g);
-  w = __fadd_rn(w, __fmul_rn(h, -1.0f));
+  g = g * eps;
+  const float hm = h * mom;
+  h = hm + g;
+  w = w - h;
 }
 
 __global__ void sgd_kernel(float* __restrict__ g, float* __restrict__ w, float* __restrict__ h, size_t n, bool vec, float l2, float clip,

@@ -19,6 +19,8 @@
 // contiguous dimension of every activation, so it is mapped to the D *column* (lane) dimension:
 // loads of 4 consecutive images per lane are one ds_read_b128 / global dwordx4 and stores are
 // 512 contiguous bytes per half-wave.  64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak (fp32 matrix).
+#include <string>
+
 #include "common.h"
 
 namespace chip {
@@ -545,6 +547,10 @@ namespace {
 
 constexpr int kTargetBlocks = 512;  // ~2 resident blocks per CU
 
+// tag + algorithmic flops of the call being dispatched (consumed by KernelTimer in the launchers)
+const char* t_op = "";
+double t_flops = 0.0;
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename Kern>
@@ -579,14 +585,19 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   p.partial = splits > 1 ? static_cast<float*>(workspace(sizeof(float) * dst_elems * splits)) : nullptr;
   dim3 grid(((tiles + 7) / 8) * 8, splits);
   dim3 block(WR * WC * 64);
-  if (vec) {
-    allow_big_lds(gg_kernel<WR, WC, MT, AK, true>, lds);
-    hipLaunchKernelGGL((gg_kernel<WR, WC, MT, AK, true>), grid, block, lds, stream(), p);
-  } else {
-    allow_big_lds(gg_kernel<WR, WC, MT, AK, false>, lds);
-    hipLaunchKernelGGL((gg_kernel<WR, WC, MT, AK, false>), grid, block, lds, stream(), p);
+  static const std::string kname = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + (AK ? "kc" : "rc") + ">";
+  {
+    KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0);
+    if (vec) {
+      allow_big_lds(gg_kernel<WR, WC, MT, AK, true>, lds);
+      hipLaunchKernelGGL((gg_kernel<WR, WC, MT, AK, true>), grid, block, lds, stream(), p);
+    } else {
+      allow_big_lds(gg_kernel<WR, WC, MT, AK, false>, lds);
+      hipLaunchKernelGGL((gg_kernel<WR, WC, MT, AK, false>), grid, block, lds, stream(), p);
+    }
   }
   if (splits > 1) {
+    KernelTimer timer("gg_reduce_kernel", t_op, 0.0, sizeof(float) * (double)dst_elems * (splits + 1));
     size_t nb = (dst_elems + 255) / 256;
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(gg_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream(), p.dst, p.partial, p.bias, dst_elems, p.slab,
@@ -636,14 +647,19 @@ void wg_launch_cfg(WGParams& p, bool vec) {
   p.splits = splits;
   p.partial = splits > 1 ? static_cast<float*>(workspace(sizeof(float) * total * splits)) : nullptr;
   dim3 grid(tiles, splits), block(WM * WN * 64);
-  if (vec) {
-    allow_big_lds(wg_kernel<WM, WN, MT, NTL, true>, lds);
-    hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, true>), grid, block, lds, stream(), p);
-  } else {
-    allow_big_lds(wg_kernel<WM, WN, MT, NTL, false>, lds);
-    hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, false>), grid, block, lds, stream(), p);
+  static const std::string kname = "wg_kernel<" + std::to_string(WM) + "," + std::to_string(WN) + "," + std::to_string(MT) + "," + std::to_string(NTL) + ">";
+  {
+    KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0);
+    if (vec) {
+      allow_big_lds(wg_kernel<WM, WN, MT, NTL, true>, lds);
+      hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, true>), grid, block, lds, stream(), p);
+    } else {
+      allow_big_lds(wg_kernel<WM, WN, MT, NTL, false>, lds);
+      hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, false>), grid, block, lds, stream(), p);
+    }
   }
   if (splits > 1) {
+    KernelTimer timer("wg_reduce_kernel", t_op, 0.0, sizeof(float) * (double)total * (splits + 1));
     size_t nb = (total + 255) / 256;
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream(), p.dst, p.partial, total, splits, p.scaleTargets,
@@ -709,6 +725,8 @@ void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* tar
   p.nblk = divup(g.N, 128); p.ncols = p.G * p.nblk;
   p.scaleTargets = scaleTargets; p.relu = relu;
   const bool vec = g.N % 4 == 0 && g.F % 4 == 0 && aligned16(p.A) && aligned16(p.src) && aligned16(p.dst);
+  t_op = "conv_fprop";
+  t_flops = 2.0 * g.N * p.G * (double)g.F * p.K;
   gg_run<false>(p, vec, (size_t)g.N * p.DP * g.F);
   note_kernel("gg_kernel(fprop)", 2.0 * g.N * p.G * (double)g.F * p.K, p.row_tiles * p.col_tiles, p.splits);
 }
@@ -764,6 +782,7 @@ void convDownGemm(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* 
       if (welems > 0) {
         int nb = (int)((welems + 255) / 256);
         if (nb > 2048) nb = 2048;
+        KernelTimer timer("dgrad_filter_kernel", "conv_dgrad", 0.0, 8.0 * welems);
         hipLaunchKernelGGL(dgrad_filter_kernel, dim3(nb), dim3(256), 0, stream(), filters->data_device, wc, g.F, g.C, g.Ky,
                            g.Kx, cy, cx, g.sy, g.sx, TYc, TXc);
       }
@@ -776,6 +795,8 @@ void convDownGemm(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* 
       p.nblk = divup(g.N, 128); p.ncols = p.G * p.nblk;
       p.scaleTargets = scaleTargets; p.relu = 0;
       const bool vec = g.N % 4 == 0 && g.C % 4 == 0 && aligned16(p.src) && aligned16(p.dst);
+      t_op = "conv_dgrad";
+      t_flops = 2.0 * g.N * p.G * (double)g.C * p.K;
       gg_run<false>(p, vec, 0);
       flops += 2.0 * g.N * p.G * (double)g.C * p.K;
       blocks += p.row_tiles * p.col_tiles;
@@ -800,6 +821,8 @@ void convOutpGemm(cudamat* images, cudamat* derivs, cudamat* targets, Shape4D* i
   p.nchunk = divup(g.N, WG_NB); p.chunks_total = p.M * p.nchunk;
   p.scaleTargets = scaleTargets; p.scaleOutput = scaleOutput;
   const bool vec = g.N % 4 == 0 && aligned16(p.src) && aligned16(p.dout);
+  t_op = "conv_wgrad";
+  t_flops = 2.0 * g.N * p.M * (double)g.F * p.K;
   wg_launch(p, vec);
   note_kernel("wg_kernel(wgrad)", 2.0 * g.N * p.M * (double)g.F * p.K, p.k_tiles * p.f_tiles, p.splits);
 }
@@ -835,6 +858,8 @@ int dotBiasAct(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target, flo
     p.nblk = divup(m, 128); p.ncols = p.nblk;
     p.scaleTargets = beta; p.relu = relu;
     const bool base_vec = m % 4 == 0 && aligned16(p.src) && aligned16(p.dst) && aligned16(p.A);
+    t_op = t2 ? "fc_fprop" : "fc_dgrad";
+    t_flops = 2.0 * m * (double)n * K;
     if (t2) {   // NT: A[r=f + F*k=d]
       gg_run<false>(p, base_vec && n % 4 == 0, (size_t)m * n);
     } else {    // NN: A[k=f + F*r=d]
@@ -853,6 +878,8 @@ int dotBiasAct(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target, flo
     p.nchunk = divup(K, WG_NB); p.chunks_total = p.nchunk;
     p.scaleTargets = beta; p.scaleOutput = alpha;
     const bool vec = K % 4 == 0 && aligned16(p.src) && aligned16(p.dout);
+    t_op = "fc_wgrad";
+    t_flops = 2.0 * m * (double)n * K;
     wg_launch(p, vec);
     note_kernel("wg_kernel(fc TN)", 2.0 * m * (double)n * K, p.k_tiles * p.f_tiles, p.splits);
     return launch_status();

@@ -261,6 +261,8 @@ void pool_fwd(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, const
   const PoolGeo g = pool_geo(is, ts, d, images, targets);
   const bool vec = g.N % 4 == 0 && a16(images->data_device) && a16(targets->data_device);
   const size_t total = (size_t)g.C * g.My * g.Mx * g.nvec;
+  // algorithmic bytes: read input once, write output once
+  KernelTimer timer(MAX ? "pool_fwd_kernel<max>" : "pool_fwd_kernel<avg>", "pool_fwd", 0.0, 4.0 * g.N * g.C * ((double)g.H * g.W + (double)g.My * g.Mx));
   hipLaunchKernelGGL(pool_fwd_kernel<MAX>, dim3(grid_for(total)), dim3(256), 0, stream(), images->data_device, targets->data_device, g, st,
                      so, vec);
 }
@@ -272,6 +274,8 @@ void pool_undo(cudamat* images, cudamat* grads, cudamat* acts, cudamat* targets,
   const bool vec = g.N % 4 == 0 && a16(grads->data_device) && a16(targets->data_device) &&
                    (!MAX || (a16(images->data_device) && a16(acts->data_device)));
   const size_t total = (size_t)g.C * g.H * g.W * g.nvec;
+  KernelTimer timer(MAX ? "pool_undo_kernel<max>" : "pool_undo_kernel<avg>", "pool_undo", 0.0,
+                    4.0 * g.N * g.C * ((MAX ? 2.0 : 1.0) * g.H * g.W + (MAX ? 2.0 : 1.0) * g.My * g.Mx + (st != 0.f ? (double)g.H * g.W : 0.0)));
   hipLaunchKernelGGL(pool_undo_kernel<MAX>, dim3(grid_for(total)), dim3(256), 0, stream(), MAX ? images->data_device : nullptr,
                      grads->data_device, MAX ? acts->data_device : nullptr, targets->data_device, g, st, vec);
 }
@@ -312,6 +316,7 @@ void ResponseNormCrossMapGemm(cudamat* images, cudamat* targets, int numFilters,
   CHIP_REQUIRE(numel(targets) == total && numFilters > 0 && total % numFilters == 0 && sizeF > 0);
   const size_t locs = total / numFilters;
   const bool vec = locs % 4 == 0 && a16(images->data_device) && a16(targets->data_device);
+  KernelTimer timer("rnorm_fwd_kernel", "rnorm_fwd", 0.0, 8.0 * total);
   hipLaunchKernelGGL(rnorm_fwd_kernel, dim3(grid_for((locs + 3) / 4)), dim3(256), 0, stream(), images->data_device, targets->data_device, locs,
                      numFilters, sizeF, addScale, powScale, blocked, vec);
 }
@@ -329,6 +334,7 @@ void ResponseNormCrossMapUndoGemm(cudamat* outGrads, cudamat* inputs, cudamat* t
   float* scaled = prod + padded;
   const bool vec = locs % 4 == 0 && a16(outGrads->data_device) && a16(inputs->data_device) && a16(targets->data_device);
   const int grid = grid_for((locs + 3) / 4);
+  KernelTimer timer("rnorm_undo_kernels", "rnorm_undo", 0.0, 12.0 * total);
   hipLaunchKernelGGL(rnorm_undo1_kernel, dim3(grid), dim3(256), 0, stream(), outGrads->data_device, inputs->data_device, prod, scaled, locs,
                      numFilters, sizeF, addScale, powScale, blocked, vec);
   hipLaunchKernelGGL(rnorm_undo2_kernel, dim3(grid), dim3(256), 0, stream(), inputs->data_device, prod, scaled, targets->data_device, locs,

@@ -1,7 +1,9 @@
 // Library state, memory plumbing and views: the non-compute part of the cudamat ABI
 // (reference cudamat/cudamat.cu:40-160,360-640), re-done over the HIP runtime.
 #include <cstring>
+#include <map>
 #include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -35,6 +37,39 @@ void note_kernel(const char* name, double flops, int blocks, int split_k) {
   g_info.flops = flops;
   g_info.grid_blocks = blocks;
   g_info.split_k = split_k;
+}
+
+// ---- per-launch HIP-event timing ------------------------------------------------------------------
+namespace {
+struct ProfRec {
+  std::string name, op;
+  double flops, bytes;
+  hipEvent_t start, stop;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_event_pool;
+hipEvent_t get_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  CHIP_CHECK(hipEventCreate(&e));
+  return e;
+}
+}  // namespace
+
+KernelTimer::KernelTimer(const char* name, const char* op, double flops, double bytes) : slot(-1) {
+  if (!g_prof_on) return;
+  ProfRec r{name, op, flops, bytes, get_event(), get_event()};
+  CHIP_CHECK(hipEventRecord(r.start, g_stream));
+  g_prof.push_back(r);
+  slot = (int)g_prof.size() - 1;
+}
+KernelTimer::~KernelTimer() {
+  if (slot >= 0) CHIP_CHECK(hipEventRecord(g_prof[slot].stop, g_stream));
 }
 
 __global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
@@ -89,6 +124,36 @@ int cuda_set_device(int deviceId) { return hipSetDevice(deviceId) == hipSuccess 
 void cuda_sync_threads(void) { CHIP_CHECK(hipStreamSynchronize(g_stream)); }
 
 void convnet_hip_last_kernel_info(ConvnetHipKernelInfo* out) { *out = g_info; }
+
+void convnet_hip_profile_enable(int on) { g_prof_on = on != 0; }
+
+// Synchronises the stream, aggregates the recorded launches by (kernel, op) into `buf` as text lines
+// "kernel|op|launches|total_ms|total_flops|total_bytes" and clears the records.  Returns the
+// number of bytes written (0 if nothing was recorded or the buffer is too small).
+size_t convnet_hip_profile_report(char* buf, size_t cap) {
+  if (g_prof.empty()) return 0;
+  hipStreamSynchronize(g_stream);
+  struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
+  std::map<std::string, Agg> agg;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.start, r.stop);
+    Agg& a = agg[r.name + "|" + r.op];
+    a.n++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+    g_event_pool.push_back(r.start);
+    g_event_pool.push_back(r.stop);
+  }
+  g_prof.clear();
+  std::string out;
+  char line[512];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof line, "%s|%ld|%.6f|%.6e|%.6e\n", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes);
+    out += line;
+  }
+  if (out.size() + 1 > cap) return 0;
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return out.size();
+}
 
 int allocate_device_memory(cudamat* mat) {
   const size_t bytes = numel(mat) * sizeof(float);

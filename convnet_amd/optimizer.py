@@ -1,0 +1,126 @@
+"""Optimizers — mirror of src/optimizer.{h,cc} for the hot path (SGD + momentum, the only optimizer
+the target configs use; Adagrad/RMSProp/LBFGS are out of scope)."""
+import math
+
+from .matrix import Matrix
+
+
+class Optimizer:
+    @staticmethod
+    def ChooseOptimizer(config):
+        # src/optimizer.cc:8-29
+        if config.optimizer_type == "STOCHASTIC_GRADIENT_DESCENT":
+            return SGDOptimizer(config)
+        raise SystemExit(f"Undefined optimizer {config.optimizer_type} (only SGD is on the hot path).")
+
+    def __init__(self, c):
+        self.epsilon_decay_type_ = c.epsilon_decay
+        self.epsilon_ = c.epsilon
+        self.minimum_epsilon_ = c.minimum_epsilon
+        self.decay_factor_ = c.decay_factor
+        self.epsilon_decay_timescale_ = c.epsilon_decay_timescale
+        self.start_optimization_after_ = c.start_optimization_after
+        self.l2_decay_ = c.l2_decay
+        self.weight_norm_limit_ = c.weight_norm_limit
+        self.weight_norm_constraint_ = c.weight_norm_constraint
+        self.step_ = 0
+        if c.shared_prior:
+            raise SystemExit("shared_prior is out of scope")
+
+    def ReduceLearningRate(self, factor):
+        self.epsilon_ *= factor
+
+    def ApplyConstraints(self, parameter):
+        # src/optimizer.cc:75-81 (axis=1: per output unit)
+        if self.weight_norm_constraint_ > 0:
+            parameter.NormLimitByAxis(1, self.weight_norm_constraint_, True)
+        elif self.weight_norm_limit_ > 0:
+            parameter.NormLimitByAxis(1, self.weight_norm_limit_, False)
+
+    def GetDecayedEpsilon(self):
+        # src/optimizer.cc:83-104
+        eps = self.epsilon_
+        ts = self.epsilon_decay_timescale_
+        if ts > 0 and self.epsilon_decay_type_ != "NONE":
+            f = float(self.step_) / ts
+            t = self.epsilon_decay_type_
+            if t == "EXPONENTIAL":
+                eps = self.epsilon_ * math.exp(-f)
+            elif t == "INVERSE_T":
+                eps = self.epsilon_ / (1 + f)
+            elif t == "LINEAR":
+                eps = self.epsilon_ * (1 - f) + self.minimum_epsilon_ * f if f < 1 else self.minimum_epsilon_
+            elif t == "EXPONENTIAL_STEP":
+                eps = self.epsilon_ * math.pow(self.decay_factor_, self.step_ // ts)
+            else:
+                raise SystemExit("Unknown epsilon decay rule.")
+        return max(eps, self.minimum_epsilon_)
+
+    def NotifyStart(self, parameter):
+        pass
+
+    def AllocateMemory(self, rows, cols):
+        pass
+
+    def IsAllocated(self):
+        return False
+
+
+class SGDOptimizer(Optimizer):
+    def __init__(self, c):
+        super().__init__(c)
+        self.gradient_clip_ = c.gradient_clip
+        self.initial_momentum_ = c.initial_momentum
+        self.final_momentum_ = c.final_momentum
+        self.momentum_transition_timescale_ = c.momentum_transition_timescale
+        self.nesterov_momentum_ = c.nesterov_momentum
+        self.gradient_history_ = Matrix()
+        self.fused = False
+
+    def AllocateMemory(self, rows, cols, storage=None):
+        """``storage``: optional Matrix slice of a flat history buffer (the reference allocates one
+        matrix per tensor, src/optimizer.cc:131-134; a flat buffer makes the state contiguous)."""
+        if storage is not None:
+            self.gradient_history_ = storage
+            self.gradient_history_.Reshape(rows, cols)
+        else:
+            self.gradient_history_.AllocateGPUMemory(rows, cols, "optimizer")
+        self.gradient_history_.Set(0.0)
+
+    def IsAllocated(self):
+        return self.gradient_history_.GetNumEls() > 0
+
+    def GetMomentum(self):
+        # src/optimizer.cc:158-165
+        if self.momentum_transition_timescale_ > 0:
+            return self.initial_momentum_ + (self.final_momentum_ - self.initial_momentum_) * \
+                (1 - math.exp(-float(self.step_) / self.momentum_transition_timescale_))
+        return self.final_momentum_
+
+    def NotifyStart(self, parameter):
+        if self.nesterov_momentum_:
+            self.gradient_history_.Mult(self.GetMomentum())
+            parameter.Add(self.gradient_history_, -1)
+
+    def Optimize(self, gradient, parameter):
+        # src/optimizer.cc:174-200
+        if self.step_ >= self.start_optimization_after_:
+            epsilon = self.GetDecayedEpsilon()
+            if self.fused and not self.nesterov_momentum_:
+                Matrix.SGDMomentumStep(gradient, parameter, self.gradient_history_, self.l2_decay_,
+                                       self.gradient_clip_, epsilon, self.GetMomentum())
+            else:
+                if self.l2_decay_ > 0:
+                    gradient.Add(parameter, self.l2_decay_)
+                if self.gradient_clip_ > 0:
+                    gradient.UpperBoundMod(self.gradient_clip_)
+                gradient.Mult(epsilon)
+                if not self.nesterov_momentum_:
+                    self.gradient_history_.Mult(self.GetMomentum())
+                self.gradient_history_.Add(gradient)
+                if self.nesterov_momentum_:
+                    parameter.Add(gradient, -1)
+                else:
+                    parameter.Add(self.gradient_history_, -1)
+            self.ApplyConstraints(parameter)
+        self.step_ += 1

@@ -245,6 +245,11 @@ typedef struct ConvnetHipKernelInfo {
   int split_k;
 } ConvnetHipKernelInfo;
 void convnet_hip_last_kernel_info(ConvnetHipKernelInfo* out);
+/* Per-launch HIP-event timing on the library stream (used by bench.py's roofline leg).  While enabled
+ * every conv/FC/pool/norm launch is bracketed by two hipEventRecord calls; the report synchronises,
+ * aggregates by (kernel, op) into text lines "kernel|op|launches|total_ms|total_flops|total_bytes". */
+void convnet_hip_profile_enable(int on);
+size_t convnet_hip_profile_report(char* buf, size_t cap);
 
 #ifdef __cplusplus
 }
