@@ -15,6 +15,8 @@ hipStream_t stream();
 // Grow-only scratch arena.  Returns a device pointer valid until the next call that asks for more
 // than the current capacity (growth synchronises the stream first, so in-flight users stay valid).
 void* workspace(size_t bytes);
+// 256 bytes of device zeros (allocated once): where branch-free kernels point out-of-range loads.
+const float* zero_page();
 void set_last_error(const char* msg);
 void note_kernel(const char* name, double flops, int blocks, int split_k);
 

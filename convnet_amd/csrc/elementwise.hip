@@ -92,6 +92,35 @@ __global__ void colsum_block_kernel(const float* __restrict__ mat, float* __rest
   if (threadIdx.x == 0) target[blockIdx.x] = (p != 0.f ? p * target[blockIdx.x] : 0.f) + mult * s;
 }
 
+// few, very long columns (shared-bias gradient: 96 columns x 774,400 rows for conv1): split every column
+// over gridDim.y blocks into a slab of partial sums, then one tiny deterministic finishing pass.
+template <bool SQ>
+__global__ void colsum_split_kernel(const float* __restrict__ mat, float* __restrict__ part, int rows, int per) {
+  __shared__ float sh[8];
+  const float* col = mat + (size_t)blockIdx.x * rows;
+  const int beg = blockIdx.y * per, end = min(rows, beg + per);
+  float s = 0.f;
+  if (((reinterpret_cast<uintptr_t>(col) & 15) == 0) && (rows & 3) == 0 && (per & 3) == 0) {
+    const f32x4* c4 = reinterpret_cast<const f32x4*>(col);
+    for (int i = (beg >> 2) + threadIdx.x; i < (end >> 2); i += blockDim.x) {
+      const f32x4 v = c4[i];
+      s += SQ ? (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]) : (v[0] + v[1]) + (v[2] + v[3]);
+    }
+  } else {
+    for (int i = beg + threadIdx.x; i < end; i += blockDim.x) s += SQ ? col[i] * col[i] : col[i];
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+__global__ void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ target, int cols, int splits, float mult, float p) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += part[(size_t)k * cols + j];
+  target[j] = (p != 0.f ? p * target[j] : 0.f) + mult * s;
+}
+
 // short columns: one wave per column, 4 columns per block
 template <bool SQ>
 __global__ void colsum_wave_kernel(const float* __restrict__ mat, float* __restrict__ target, int rows, int cols, float mult, float p) {
@@ -124,7 +153,17 @@ int axis_sum(cudamat* mat, cudamat* target, int axis, float mult, float p) {
   const int rows = mat->size[0], cols = mat->size[1];
   if (axis == 0) {
     if (target->size[0] != 1 || target->size[1] != cols) return ERROR_INCOMPATIBLE_DIMENSIONS;
-    if (rows >= 2048)
+    if (rows >= 32768 && cols < 1024) {
+      int splits = 2048 / cols;
+      if (splits > rows / 4096) splits = rows / 4096;
+      if (splits < 2) splits = 2;
+      int per = ((divup(rows, splits) + 3) / 4) * 4;
+      splits = divup(rows, per);
+      float* part = static_cast<float*>(workspace(sizeof(float) * (size_t)splits * cols));
+      KernelTimer timer(SQ ? "colsum_split_kernel<sq>" : "colsum_split_kernel", "colsum", 0.0, 4.0 * rows * cols);
+      hipLaunchKernelGGL(colsum_split_kernel<SQ>, dim3(cols, splits), dim3(256), 0, stream(), mat->data_device, part, rows, per);
+      hipLaunchKernelGGL(colsum_finish_kernel, dim3(divup(cols, 256)), dim3(256), 0, stream(), part, target->data_device, cols, splits, mult, p);
+    } else if (rows >= 2048)
       hipLaunchKernelGGL(colsum_block_kernel<SQ>, dim3(cols), dim3(256), 0, stream(), mat->data_device, target->data_device, rows, mult, p);
     else
       hipLaunchKernelGGL(colsum_wave_kernel<SQ>, dim3(divup(cols, 4)), dim3(256), 0, stream(), mat->data_device, target->data_device, rows, cols, mult, p);

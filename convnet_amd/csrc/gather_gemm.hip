@@ -36,6 +36,7 @@ struct GGParams {
   float* dst;
   const float* bias;  // per output row, nullable
   float* partial;     // split-K slabs, nullable
+  const float* zero;  // >= 16 bytes of zeros: target of out-of-range loads (branch-free fast path)
   int R, K, N;
   int lda;            // A[r + lda*k] (r-contiguous) or A[k + lda*r] (k-contiguous)
   int GX, G;          // output pixel grid of this launch: G = GY*GX pixels, m = oy*GX + ox
@@ -118,7 +119,74 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
 
   f32x4 ra[NA], rb[NB];
 
+  // ---- VEC fast path: incremental tap decode + branch-free loads ---------------------------------
+  // The slot -> (k-row, column) assignment never changes, so the (channel, tap_y, tap_x) decode of
+  // a slot's k is carried from chunk to chunk (k advances by BK = dch*TYX + da*TX + db each chunk,
+  // one conditional carry per digit) instead of being re-divided, and out-of-range taps / rows /
+  // images read a 16-byte zero page instead of branching.  ~25 VALU per slot per chunk.
+  const int TYn = p.TYX / p.TX;
+  const int dch = BK / p.TYX, drem = BK - dch * p.TYX;
+  const int da = drem / p.TX, db = drem - da * p.TX;
+  int s_k[NB], s_ch[NB], s_a[NB], s_b[NB];
+  const float* a_ptr[NA];
+  int a_k[NA];
+  bool a_ok[NA];
+  if (VEC) {
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int k = kbeg + b_krow[it];
+      const int ch = k / p.TYX, tap = k - ch * p.TYX;
+      s_k[it] = k;
+      s_ch[it] = ch;
+      s_a[it] = tap / p.TX;
+      s_b[it] = tap - s_a[it] * p.TX;
+      b_ok[it] = b_ok[it] && b_n[it] < N;
+    }
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int idx = tid + it * NT;
+      if (!A_KCONTIG) {
+        const int krow = idx / (ROWS / 4), c4 = idx % (ROWS / 4);
+        const int r = r0 + 4 * c4;
+        a_k[it] = kbeg + krow;
+        a_ok[it] = idx < BK * (ROWS / 4) && r < p.R;
+        a_ptr[it] = p.A + (size_t)p.lda * a_k[it] + r;
+      } else {
+        const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+        const int r = r0 + row;
+        a_k[it] = kbeg + 4 * c4;
+        a_ok[it] = idx < ROWS * (BK / 4) && r < p.R;
+        a_ptr[it] = p.A + (size_t)p.lda * (a_ok[it] ? r : 0) + a_k[it];
+      }
+    }
+  }
+  auto fetch_vec = [&]() {
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const bool ok = a_ok[it] && a_k[it] < kend;
+      ra[it] = ld4(ok ? a_ptr[it] : p.zero);
+      a_k[it] += BK;
+      a_ptr[it] += A_KCONTIG ? (size_t)BK : (size_t)p.lda * BK;
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int ys = b_ys0[it] + p.dir * s_a[it], xs = b_xs0[it] + p.dir * s_b[it];
+      const bool ok = b_ok[it] && s_k[it] < kend && (unsigned)ys < (unsigned)p.SH && (unsigned)xs < (unsigned)p.SW;
+      const unsigned off = (unsigned)((s_ch[it] * p.SH + ys) * p.SW + xs) * (unsigned)N + (unsigned)b_n[it];
+      rb[it] = ld4(ok ? p.src + off : p.zero);
+      s_k[it] += BK;
+      int b = s_b[it] + db, a = s_a[it] + da, ch = s_ch[it] + dch;
+      if (b >= p.TX) { b -= p.TX; a += 1; }
+      if (a >= TYn) { a -= TYn; ch += 1; }
+      s_b[it] = b; s_a[it] = a; s_ch[it] = ch;
+    }
+  };
+
   auto fetch = [&](int k0) {
+    if (VEC) {
+      fetch_vec();   // stateful: called with k0 = kbeg, kbeg+BK, ... in order
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const int idx = tid + it * NT;
@@ -345,6 +413,7 @@ struct WGParams {
   const float* dout;  // output deriv (N, M*F), M = GY*GX
   float* dst;         // dW (F, K)  column-major: dst[f + F*k]
   float* partial;     // [splits][K][F]
+  const float* zero;  // zero page for out-of-range loads
   int K, F, N;
   int GX, M;
   int TX, TYX;
@@ -418,7 +487,51 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
   if (cend > p.chunks_total) cend = p.chunks_total;
 
   f32x4 ra[NA], rb[NB];
+
+  // ---- VEC fast path: the (pixel, image-chunk) walk is carried incrementally (no per-chunk division),
+  // every slot's address is  const(slot) + uniform(chunk)  and out-of-range loads hit the zero page.
+  unsigned a_const[NA], b_const[NB];
+  int w_m = 0, w_nc = 0, w_oy = 0, w_ox = 0;   // wave-uniform walk state
+  if (VEC) {
+    w_m = cbeg / p.nchunk;
+    w_nc = cbeg - w_m * p.nchunk;
+    w_oy = w_m / p.GX;
+    w_ox = w_m - w_oy * p.GX;
+#pragma unroll
+    for (int it = 0; it < NA; ++it) a_const[it] = (unsigned)(a_choff[it] + a_ta[it] * p.SW + a_tb[it]) * (unsigned)N + (unsigned)a_n[it];
+#pragma unroll
+    for (int it = 0; it < NB; ++it) b_const[it] = (unsigned)(b_ok[it] ? b_f[it] : 0) * (unsigned)p.M * (unsigned)N + (unsigned)b_n[it];
+  }
+  auto fetch_vec = [&]() {
+    const int ysb = w_oy * p.ssy + p.y0, xsb = w_ox * p.ssx + p.x0;
+    const int nb = w_nc * WG_NB;
+    const unsigned ua = (unsigned)(ysb * p.SW + xsb) * (unsigned)N + (unsigned)nb;
+    const unsigned ub = (unsigned)w_m * (unsigned)N + (unsigned)nb;
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const bool ok = a_ok[it] && (unsigned)(ysb + a_ta[it]) < (unsigned)p.SH && (unsigned)(xsb + a_tb[it]) < (unsigned)p.SW && nb + a_n[it] < N;
+      ra[it] = ld4(ok ? p.src + (a_const[it] + ua) : p.zero);
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const bool ok = b_ok[it] && nb + b_n[it] < N;
+      rb[it] = ld4(ok ? p.dout + (b_const[it] + ub) : p.zero);
+    }
+    if (++w_nc == p.nchunk) {
+      w_nc = 0;
+      ++w_m;
+      if (++w_ox == p.GX) {
+        w_ox = 0;
+        ++w_oy;
+      }
+    }
+  };
+
   auto fetch = [&](int c) {
+    if (VEC) {
+      fetch_vec();   // stateful: called for c = cbeg, cbeg+1, ... in order
+      return;
+    }
     const int m = c / p.nchunk, nc = c - m * p.nchunk;
     const int oy = m / p.GX, ox = m - oy * p.GX;
     const int ysb = oy * p.ssy + p.y0, xsb = ox * p.ssx + p.x0;
@@ -569,6 +682,7 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   const size_t lds = sizeof(float) * 2 * (A_STAGE + B_STAGE);
   p.row_tiles = divup(p.R, ROWS);
   p.col_tiles = divup(p.ncols, WC);
+  p.zero = zero_page();
   const int tiles = p.row_tiles * p.col_tiles;
   const int kchunks = divup(p.K, BK);
   int splits = 1;
@@ -631,6 +745,7 @@ void wg_launch_cfg(WGParams& p, bool vec) {
   const size_t lds = sizeof(float) * 2 * (KT + FT) * WG_PITCH;
   p.k_tiles = divup(p.K, KT);
   p.f_tiles = divup(p.F, FT);
+  p.zero = zero_page();
   const int tiles = p.k_tiles * p.f_tiles;
   const size_t total = (size_t)p.K * p.F;
   int splits = 1;

@@ -137,14 +137,21 @@ __device__ __forceinline__ void win_bwd(int j, int C, int sizeF, bool blocked, i
 }
 
 __global__ void rnorm_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, size_t locs, int C, int sizeF, float addScale,
-                                 float powScale, bool blocked, bool vec) {
+                                 float powScale, bool blocked, bool vec, int cseg, int nseg) {
   const size_t nq = (locs + 3) >> 2;
-  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
-    const size_t l = q << 2;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq * nseg; q += (size_t)gridDim.x * blockDim.x) {
+    const int seg = (int)(q / nq);
+    const size_t l = (q % nq) << 2;
+    const int j0 = seg * cseg, j1 = min(C, j0 + cseg);
     const int rem = (int)min((size_t)4, locs - l);
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    int ps = 0, pe = 0;
-    for (int j = 0; j < C; ++j) {
+    int ps, pe;
+    {
+      int e0;
+      win_fwd(j0, C, sizeF, blocked, ps, e0);
+      pe = ps;   // the first iteration adds the whole window of j0 directly
+    }
+    for (int j = j0; j < j1; ++j) {
       int s, e;
       win_fwd(j, C, sizeF, blocked, s, e);
       for (int i = ps; i < s; ++i) {
@@ -169,14 +176,21 @@ __global__ void rnorm_fwd_kernel(const float* __restrict__ in, float* __restrict
 // pass 1 of undo: den = (1+a*sum)^(-b-1); prod = dout*in*den; scaled = dout*den^(b/(b+1))
 __global__ void rnorm_undo1_kernel(const float* __restrict__ dout, const float* __restrict__ in, float* __restrict__ prod,
                                    float* __restrict__ scaled, size_t locs, int C, int sizeF, float addScale, float powScale, bool blocked,
-                                   bool vec) {
+                                   bool vec, int cseg, int nseg) {
   const size_t nq = (locs + 3) >> 2;
-  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
-    const size_t l = q << 2;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq * nseg; q += (size_t)gridDim.x * blockDim.x) {
+    const int seg = (int)(q / nq);
+    const size_t l = (q % nq) << 2;
+    const int j0 = seg * cseg, j1 = min(C, j0 + cseg);
     const int rem = (int)min((size_t)4, locs - l);
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    int ps = 0, pe = 0;
-    for (int j = 0; j < C; ++j) {
+    int ps, pe;
+    {
+      int e0;
+      win_fwd(j0, C, sizeF, blocked, ps, e0);
+      pe = ps;   // the first iteration adds the whole window of j0 directly
+    }
+    for (int j = j0; j < j1; ++j) {
       int s, e;
       win_fwd(j, C, sizeF, blocked, s, e);
       for (int i = ps; i < s; ++i) {
@@ -207,15 +221,22 @@ __global__ void rnorm_undo1_kernel(const float* __restrict__ dout, const float* 
 // pass 2: target_j = scaled_j - 2ab * in_j * sum_{i in win^-1(j)} prod_i
 __global__ void rnorm_undo2_kernel(const float* __restrict__ in, const float* __restrict__ prod, const float* __restrict__ scaled,
                                    float* __restrict__ out, size_t locs, int C, int sizeF, float addScale, float powScale, bool blocked,
-                                   bool vec) {
+                                   bool vec, int cseg, int nseg) {
   const size_t nq = (locs + 3) >> 2;
   const float k2 = 2 * addScale * powScale;
-  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
-    const size_t l = q << 2;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq * nseg; q += (size_t)gridDim.x * blockDim.x) {
+    const int seg = (int)(q / nq);
+    const size_t l = (q % nq) << 2;
+    const int j0 = seg * cseg, j1 = min(C, j0 + cseg);
     const int rem = (int)min((size_t)4, locs - l);
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    int ps = 0, pe = 0;
-    for (int j = 0; j < C; ++j) {
+    int ps, pe;
+    {
+      int e0;
+      win_bwd(j0, C, sizeF, blocked, ps, e0);
+      pe = ps;   // the first iteration adds the whole window of j0 directly
+    }
+    for (int j = j0; j < j1; ++j) {
       int s, e;
       win_bwd(j, C, sizeF, blocked, s, e);
       for (int i = ps; i < s; ++i) sum = sum - ldv(prod + (size_t)i * locs + l, 0, rem, vec);
@@ -235,6 +256,21 @@ __global__ void rnorm_undo2_kernel(const float* __restrict__ in, const float* __
 namespace {
 
 inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Channel segmentation of the response-norm walk: a lane slides its window over `cseg` channels only
+// (its first window is summed directly), so (location quads) x (segments) lanes are in flight instead of
+// one long dependent chain per location.  Segments are kept >= the window so the direct first sum
+// costs at most as much as the slide it replaces.
+inline void rnorm_segments(size_t quads, int C, int sizeF, int& cseg, int& nseg) {
+  const size_t want = size_t(1) << 20;   // ~1M lanes: 4 waves per SIMD on 256 CUs
+  int n = (int)((want + quads - 1) / quads);
+  int max_n = C / (sizeF > 8 ? sizeF : 8);
+  if (max_n < 1) max_n = 1;
+  if (n > max_n) n = max_n;
+  if (n < 1) n = 1;
+  cseg = (C + n - 1) / n;
+  nseg = (C + cseg - 1) / cseg;
+}
 
 inline int grid_for(size_t items) {
   size_t b = (items + 255) / 256;
@@ -317,8 +353,10 @@ void ResponseNormCrossMapGemm(cudamat* images, cudamat* targets, int numFilters,
   const size_t locs = total / numFilters;
   const bool vec = locs % 4 == 0 && a16(images->data_device) && a16(targets->data_device);
   KernelTimer timer("rnorm_fwd_kernel", "rnorm_fwd", 0.0, 8.0 * total);
-  hipLaunchKernelGGL(rnorm_fwd_kernel, dim3(grid_for((locs + 3) / 4)), dim3(256), 0, stream(), images->data_device, targets->data_device, locs,
-                     numFilters, sizeF, addScale, powScale, blocked, vec);
+  int cseg, nseg;
+  rnorm_segments((locs + 3) / 4, numFilters, sizeF, cseg, nseg);
+  hipLaunchKernelGGL(rnorm_fwd_kernel, dim3(grid_for((locs + 3) / 4 * nseg)), dim3(256), 0, stream(), images->data_device, targets->data_device, locs,
+                     numFilters, sizeF, addScale, powScale, blocked, vec, cseg, nseg);
 }
 void ResponseNormCrossMap(cudamat* images, cudamat* targets, int numFilters, int sizeF, float addScale, float powScale, bool blocked) {
   ResponseNormCrossMapGemm(images, targets, numFilters, sizeF, addScale, powScale, blocked);
@@ -333,12 +371,14 @@ void ResponseNormCrossMapUndoGemm(cudamat* outGrads, cudamat* inputs, cudamat* t
   float* prod = static_cast<float*>(workspace(sizeof(float) * padded * 2));
   float* scaled = prod + padded;
   const bool vec = locs % 4 == 0 && a16(outGrads->data_device) && a16(inputs->data_device) && a16(targets->data_device);
-  const int grid = grid_for((locs + 3) / 4);
+  int cseg, nseg;
+  rnorm_segments((locs + 3) / 4, numFilters, sizeF, cseg, nseg);
+  const int grid = grid_for((locs + 3) / 4 * nseg);
   KernelTimer timer("rnorm_undo_kernels", "rnorm_undo", 0.0, 12.0 * total);
   hipLaunchKernelGGL(rnorm_undo1_kernel, dim3(grid), dim3(256), 0, stream(), outGrads->data_device, inputs->data_device, prod, scaled, locs,
-                     numFilters, sizeF, addScale, powScale, blocked, vec);
+                     numFilters, sizeF, addScale, powScale, blocked, vec, cseg, nseg);
   hipLaunchKernelGGL(rnorm_undo2_kernel, dim3(grid), dim3(256), 0, stream(), inputs->data_device, prod, scaled, targets->data_device, locs,
-                     numFilters, sizeF, addScale, powScale, blocked, vec);
+                     numFilters, sizeF, addScale, powScale, blocked, vec, cseg, nseg);
 }
 void ResponseNormCrossMapUndo(cudamat* outGrads, cudamat* inputs, cudamat* /*acts*/, cudamat* targets, int numFilters, int sizeF,
                               float addScale, float powScale, bool blocked) {

@@ -30,6 +30,15 @@ void* workspace(size_t bytes) {
   return g_ws;
 }
 
+const float* zero_page() {
+  static float* z = nullptr;
+  if (!z) {
+    CHIP_CHECK(hipMalloc((void**)&z, 256));
+    CHIP_CHECK(hipMemset(z, 0, 256));
+  }
+  return z;
+}
+
 void set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
 
 void note_kernel(const char* name, double flops, int blocks, int split_k) {
