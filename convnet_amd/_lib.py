@@ -102,6 +102,9 @@ def _load():
     sig("convOutpGemm", None, M, M, M, S, S, S, ConvDesc, F, F)
     sig("convOutp", None, M, M, M, S, S, S, ConvDesc, I, I, F, F)
     sig("convUpBiasAct", None, M, M, M, M, S, S, S, ConvDesc, F, I)
+    sig("convDownMask", None, M, M, M, M, S, S, S, ConvDesc, F, F)
+    sig("dotMask", I, M, M, M, M, F, F, F)
+    sig("MaxPoolUndoRelu", None, M, M, M, M, S, S, ConvDesc, F)
     for n in ("MaxPoolGemm", "AvgPoolGemm"):
         sig(n, None, M, M, S, S, ConvDesc, F, F)
     for n in ("MaxPool", "AvgPool"):
@@ -143,6 +146,7 @@ def _load():
     sig("get_softmax_cross_entropy_row_major", I, M, M, M, F)
     sig("softmax_ce_grad_correct", I, M, M, M, M, M, F)
     sig("sgd_momentum_step", I, M, M, M, F, F, F, F)
+    sig("sgd_momentum_step_normlimit", I, M, M, M, F, F, F, F, F, I)
     R = P(rnd_struct)
     sig("init_random", I, R, I)
     sig("fill_with_rand", I, R, M)

@@ -60,6 +60,7 @@ class ConvNet:
         self.edge_slices_ = {}   # edge -> (offset, length) in the flat buffers
         self.train_dataset_ = None
         self.correct_accum_ = None
+        self._logits_pending = set()   # output layers whose state still holds logits (fused softmax)
         self.BuildNet()
 
     def log(self, *a):
@@ -218,12 +219,12 @@ class ConvNet:
                 e.ComputeUp(src.GetState(), l.GetState(), overwrite, train, fuse_relu=(l.is_relu if fused_act else None))
             if not l.IsInput() and not fused_act:
                 if self.fused and isinstance(l, SoftmaxLayer) and l.IsOutput() and train:
-                    pass   # softmax + CE derivative + correct count are fused in ComputeDeriv
+                    self._logits_pending.add(l)   # softmax + CE derivative + correct count are fused in ComputeDeriv
                 else:
                     l.ApplyActivation()
             l.ApplyDropout(train)
 
-    def _bprop_edge(self, output, input, edge):
+    def _bprop_edge(self, output, input, edge, fuse_mask=None):
         # ConvNet::Bprop(output, input, edge), src/convnet.cc:362-375
         if edge.IsBackPropBlocked():
             return
@@ -232,19 +233,41 @@ class ConvNet:
             self.exchange_.GradReady(edge)      # wgrad of this edge is final: start its all-reduce
         if not input.IsInput():
             overwrite = input.AddOrOverwriteDeriv(edge.GetSourceSliceName())
-            edge.ComputeDown(output.GetDeriv(), input.GetState(), output.GetState(), input.GetDeriv(), overwrite)
+            if fuse_mask is not None:
+                edge.ComputeDown(output.GetDeriv(), input.GetState(), output.GetState(), input.GetDeriv(), overwrite, fuse_mask=fuse_mask)
+            else:
+                edge.ComputeDown(output.GetDeriv(), input.GetState(), output.GetState(), input.GetDeriv(), overwrite)
+
+    def _fused_down_scale(self, l):
+        """If layer l's dropout' + ReLU' can ride in its only outgoing edge's ComputeDown epilogue, return the
+        scale to apply (else None).  The reference applies them after ALL outgoing edges have accumulated
+        (src/convnet.cc:390-404), so this is only legal with exactly one edge."""
+        if not self.fused or l.IsInput() or l.IsOutput() or not l.is_relu or len(l.outgoing_edge_) != 1:
+            return None
+        e = l.outgoing_edge_[0]
+        if not e.can_fuse_mask or e.IsBackPropBlocked() or l.store_dropout_noise_:
+            return None
+        scale = 1.0 / (1 - l.dropprob_) if (l.dropprob_ > 0 and l.dropout_scale_up_at_train_time_) else 1.0
+        from .edge import MaxPoolEdge
+        if isinstance(e, MaxPoolEdge) and scale != 1.0:
+            return None
+        return scale
 
     def Bprop(self):
         for l in reversed(self.layers_):
+            scale = self._fused_down_scale(l)
             for e in l.outgoing_edge_:
-                self._bprop_edge(e.GetDest(), l, e)
+                self._bprop_edge(e.GetDest(), l, e, fuse_mask=scale)
+            if scale is not None:
+                continue   # dropout' and ReLU' were applied by the edge's epilogue
             l.ApplyDerivativeofDropout()
             if not l.IsInput() and not l.IsOutput():
                 l.ApplyDerivativeOfActivation()
 
     def ComputeDeriv(self):
         for l in self.output_layers_:
-            if self.fused and isinstance(l, SoftmaxLayer):
+            if l in self._logits_pending:
+                self._logits_pending.discard(l)
                 Matrix.SoftmaxCEGradCorrect(l.GetState(), l.GetData(), l.GetState(), l.GetDeriv(), self.correct_accum_,
                                             l.loss_function_weight_)
             else:

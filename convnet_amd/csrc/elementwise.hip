@@ -235,17 +235,75 @@ int add_row(cudamat* mat, cudamat* vec, cudamat* target, float mult) {
 }
 
 // ---- row-norm limit (axis=1: one output unit's incoming weights), eigenmat.cc:918-968 -----------------
-__global__ void normlimit_rows_kernel(const float* __restrict__ mat, float* __restrict__ target, int rows, int cols, float norm, int constraint) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows) return;
+// A (rows x cols) weight matrix is tiled as 256 rows x `chunk` columns per block; a lane owns one row of the
+// tile (loads coalesce across lanes) and keeps that row's partial sum of squares privately, so the
+// per-row norms come out deterministic (slab of partials + fixed-order finish, no atomics).
+//   pass 1 (optionally fused with the SGD update, which touches every weight anyway):  partial[chunk][row]
+//   pass 2: factor[row] = (constraint || norm_row > limit) ? limit / norm_row : 1
+//   pass 3: rescale — a block exits without touching memory when none of its 256 rows needs scaling, which
+//           is the steady state of weight_norm_limit (src/optimizer.cc:75-81).
+__device__ __forceinline__ void sgd_one(float& g, float& w, float& h, float l2, float clip, float eps, float mom);
+
+template <bool DO_SGD>
+__global__ void rows_sq_kernel(float* __restrict__ g, float* __restrict__ w, float* __restrict__ h, int rows, int cols, int chunk,
+                               float* __restrict__ partial, float l2, float clip, float eps, float mom) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int c0 = blockIdx.y * chunk, c1 = min(cols, c0 + chunk);
   float s = 0.f;
-  for (int j = 0; j < cols; ++j) {
-    const float v = mat[(size_t)i + (size_t)rows * j];
-    s += v * v;
+  for (int c = c0; c < c1; ++c) {
+    const size_t i = (size_t)r + (size_t)rows * c;
+    float wv = w[i];
+    if (DO_SGD) {
+      float gv = g[i], hv = h[i];
+      sgd_one(gv, wv, hv, l2, clip, eps, mom);
+      g[i] = gv;
+      h[i] = hv;
+      w[i] = wv;
+    }
+    s += wv * wv;
   }
+  partial[(size_t)blockIdx.y * rows + r] = s;
+}
+
+__global__ void row_factor_kernel(const float* __restrict__ partial, int nchunks, int rows, float norm, int constraint, float* __restrict__ factor) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunks; ++k) s += partial[(size_t)k * rows + r];
   s = sqrtf(s);
-  const float sc = (constraint == 1 || s > norm) ? norm / s : 1.f;
-  for (int j = 0; j < cols; ++j) target[(size_t)i + (size_t)rows * j] = mat[(size_t)i + (size_t)rows * j] * sc;
+  factor[r] = (constraint == 1 || s > norm) ? norm / s : 1.f;
+}
+
+__global__ void row_scale_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols, int chunk, const float* __restrict__ factor) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const float f = r < rows ? factor[r] : 1.f;
+  const bool in_place = src == dst;
+  if (in_place && !__syncthreads_or(f != 1.f)) return;
+  if (r >= rows) return;
+  const int c0 = blockIdx.y * chunk, c1 = min(cols, c0 + chunk);
+  for (int c = c0; c < c1; ++c) {
+    const size_t i = (size_t)r + (size_t)rows * c;
+    dst[i] = src[i] * f;
+  }
+}
+
+// grad/history may be null (plain norm limit).  Returns launch status.
+inline int rows_normlimit(float* g, float* w_in, float* w_out, float* h, int rows, int cols, float norm, int constraint, bool do_sgd,
+                          float l2, float clip, float eps, float mom) {
+  int chunk = 64;
+  while ((long)divup(rows, 256) * divup(cols, chunk) > 4096 && chunk < cols) chunk *= 2;
+  const int nchunks = divup(cols, chunk);
+  float* partial = static_cast<float*>(workspace(sizeof(float) * ((size_t)nchunks * rows + rows)));
+  float* factor = partial + (size_t)nchunks * rows;
+  dim3 grid(divup(rows, 256), nchunks);
+  if (do_sgd)
+    hipLaunchKernelGGL(rows_sq_kernel<true>, grid, dim3(256), 0, stream(), g, w_in, h, rows, cols, chunk, partial, l2, clip, eps, mom);
+  else
+    hipLaunchKernelGGL(rows_sq_kernel<false>, grid, dim3(256), 0, stream(), nullptr, w_in, nullptr, rows, cols, chunk, partial, 0.f, 0.f, 0.f, 0.f);
+  hipLaunchKernelGGL(row_factor_kernel, dim3(divup(rows, 256)), dim3(256), 0, stream(), partial, nchunks, rows, norm, constraint, factor);
+  hipLaunchKernelGGL(row_scale_kernel, grid, dim3(256), 0, stream(), w_in, w_out, rows, cols, chunk, factor);
+  return launch_status();
 }
 
 __global__ void normlimit_cols_kernel(const float* __restrict__ mat, float* __restrict__ target, int rows, float norm, int constraint) {
@@ -484,8 +542,21 @@ int normlimit_by_axis(cudamat* mat, cudamat* target, int axis, float norm, int c
   if (axis == 0)
     hipLaunchKernelGGL(normlimit_cols_kernel, dim3(cols), dim3(256), 0, stream(), mat->data_device, target->data_device, rows, norm, constraint);
   else
-    hipLaunchKernelGGL(normlimit_rows_kernel, dim3(divup(rows, 64)), dim3(64), 0, stream(), mat->data_device, target->data_device, rows, cols, norm, constraint);
+    return rows_normlimit(nullptr, mat->data_device, target->data_device, nullptr, rows, cols, norm, constraint, false, 0.f, 0.f, 0.f, 0.f);
   return launch_status();
+}
+
+// SGDOptimizer::Optimize + ApplyConstraints (src/optimizer.cc:174-200,75-81) for one (rows x cols) tensor:
+// the update pass also produces the per-row norms the constraint needs.
+int sgd_momentum_step_normlimit(cudamat* grad, cudamat* param, cudamat* history, float l2_decay, float gradient_clip, float epsilon,
+                                float momentum, float norm, int constraint) {
+  const size_t n = numel(param);
+  if (!grad->on_device || !param->on_device || !history->on_device) return ERROR_NOT_ON_DEVICE;
+  if (numel(grad) != n || numel(history) != n) return ERROR_INCOMPATIBLE_DIMENSIONS;
+  if (param->is_trans) return ERROR_TRANSPOSED;
+  if (n == 0) return 0;
+  return rows_normlimit(grad->data_device, param->data_device, param->data_device, history->data_device, param->size[0], param->size[1], norm,
+                        constraint, true, l2_decay, gradient_clip, epsilon, momentum);
 }
 
 int lower_bound_scalar(cudamat* mat, float val, cudamat* target) {

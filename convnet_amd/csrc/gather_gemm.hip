@@ -53,6 +53,8 @@ struct GGParams {
   size_t slab;        // floats per split slab (= dst extent)
   float scaleTargets;
   int relu;
+  const float* mask;  // nullable; same layout as dst: out = mask > 0 ? out * post_scale : 0  (fused ReLU' [+dropout'])
+  float post_scale;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -350,6 +352,11 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
           }
+          if (p.mask) {
+            const f32x4 mk = ld4(p.mask + (dp - p.dst));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] * p.post_scale : 0.f;
+          }
           st4(dp, v);
         } else {
 #pragma unroll
@@ -359,6 +366,7 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
               if (p.scaleTargets != 0.f) x = p.scaleTargets * dp[e] + x;
               x += bv;
               if (p.relu) x = x > 0.f ? x : 0.f;
+              if (p.mask) x = p.mask[(dp - p.dst) + e] > 0.f ? x * p.post_scale : 0.f;
               dp[e] = x;
             }
           }
@@ -378,13 +386,15 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
 
 // dst = scaleTargets*dst + sum_s slab[s]  (+bias[row], relu) over a full dst extent.
 __global__ void gg_reduce_kernel(float* __restrict__ dst, const float* __restrict__ partial, const float* __restrict__ bias,
-                                 size_t total, size_t slab, int splits, size_t per_row, float scaleTargets, int relu) {
+                                 size_t total, size_t slab, int splits, size_t per_row, float scaleTargets, int relu,
+                                 const float* __restrict__ mask, float post_scale) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += partial[(size_t)k * slab + i];
     if (scaleTargets != 0.f) s = scaleTargets * dst[i] + s;
     if (bias) s += bias[i / per_row];
     if (relu) s = s > 0.f ? s : 0.f;
+    if (mask) s = mask[i] > 0.f ? s * post_scale : 0.f;
     dst[i] = s;
   }
 }
@@ -441,11 +451,15 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
   float* As = smem;
   float* Bs = smem + 2 * A_STAGE;
 
+  // XCD-aware order: each XCD (blocks b%8) owns a contiguous run of (split, tile) pairs with the tile
+  // index fastest, so the blocks sharing one L2 walk the SAME pixel range and re-use each other's
+  // input / deriv rows from L2 instead of every XCD streaming the whole tensors.
   const int tiles = p.k_tiles * p.f_tiles;
-  const int L = blockIdx.x;
-  if (L >= tiles) return;
-  const int f_tile = L % p.f_tiles, k_tile = L / p.f_tiles;
-  const int split = blockIdx.y;
+  const int total_blocks = tiles * p.splits;
+  const int L = xcd_remap(blockIdx.x, total_blocks);
+  if (L >= total_blocks || (int)blockIdx.x >= ((total_blocks + 7) >> 3) * 8) return;
+  const int split = L / tiles, tile_id = L - split * tiles;
+  const int f_tile = tile_id % p.f_tiles, k_tile = tile_id / p.f_tiles;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
@@ -715,15 +729,17 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
     size_t nb = (dst_elems + 255) / 256;
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(gg_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream(), p.dst, p.partial, p.bias, dst_elems, p.slab,
-                       splits, (size_t)p.DP * p.N, p.scaleTargets, p.relu);
+                       splits, (size_t)p.DP * p.N, p.scaleTargets, p.relu, p.mask, p.post_scale);
   }
 }
 
 template <bool AK>
 void gg_run(GGParams& p, bool vec, size_t dst_elems) {
-  // pick the row tile (128/96/64/32) that pads the fewest rows; ties go to the larger tile.
+  // pick the row tile (128/64/32) that pads the fewest rows; ties go to the larger tile.  (The 96-row
+  // 6-wave config measured 68 TFLOP/s vs 106 for the 128-row one, so 96-row problems — conv1 fprop,
+  // conv2 dgrad — run 25 % padded on the 128-row kernel: 80 effective TFLOP/s.)
   int best = 128, best_pad = divup(p.R, 128) * 128;
-  const int cands[3] = {96, 64, 32};
+  const int cands[2] = {64, 32};
   for (int c : cands) {
     const int pad = divup(p.R, c) * c;
     if (pad < best_pad) {
@@ -761,7 +777,7 @@ void wg_launch_cfg(WGParams& p, bool vec) {
   splits = divup(p.chunks_total, p.chunks_per_split);
   p.splits = splits;
   p.partial = splits > 1 ? static_cast<float*>(workspace(sizeof(float) * total * splits)) : nullptr;
-  dim3 grid(tiles, splits), block(WM * WN * 64);
+  dim3 grid(((tiles * splits + 7) / 8) * 8), block(WM * WN * 64);
   static const std::string kname = "wg_kernel<" + std::to_string(WM) + "," + std::to_string(WN) + "," + std::to_string(MT) + "," + std::to_string(NTL) + ">";
   {
     KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0);
@@ -869,9 +885,10 @@ void convUpBiasAct(cudamat* images, cudamat* filters, cudamat* bias, cudamat* ta
   conv_up_impl(images, filters, bias, targets, is, fs, ts, d, scaleTargets, relu);
 }
 
-void convDownGemm(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* ds, Shape4D* fs, Shape4D* ts, ConvDesc d,
-                  float scaleTargets) {
+static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* ds, Shape4D* fs, Shape4D* ts, const ConvDesc& d,
+                           float scaleTargets, cudamat* mask, float post_scale) {
   const ConvGeo g = conv_geo(ts, fs, ds, d, targets, filters, derivs);
+  if (mask) CHIP_REQUIRE(numel(mask) == numel(targets));
   // one launch per stride class (cy,cx): input rows iy with (iy - pad) % sy == cy share the tap set
   // ky = cy + sy*a; their sources are oy = (iy - pad - cy)/sy - a  (pad = ConvDesc padding, <= 0).
   float* wt = static_cast<float*>(workspace(sizeof(float) * (size_t)g.C * g.F * g.Ky * g.Kx + 256 * g.sy * g.sx));
@@ -909,7 +926,8 @@ void convDownGemm(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* 
       p.DW = g.W; p.DP = g.H * g.W; p.dsy = g.sy; p.dsx = g.sx; p.dy0 = iy0; p.dx0 = ix0;
       p.nblk = divup(g.N, 128); p.ncols = p.G * p.nblk;
       p.scaleTargets = scaleTargets; p.relu = 0;
-      const bool vec = g.N % 4 == 0 && g.C % 4 == 0 && aligned16(p.src) && aligned16(p.dst);
+      p.mask = mask ? mask->data_device : nullptr; p.post_scale = post_scale;
+      const bool vec = g.N % 4 == 0 && g.C % 4 == 0 && aligned16(p.src) && aligned16(p.dst) && aligned16(p.mask);
       t_op = "conv_dgrad";
       t_flops = 2.0 * g.N * p.G * (double)g.C * p.K;
       gg_run<false>(p, vec, 0);
@@ -920,9 +938,19 @@ void convDownGemm(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* 
   note_kernel("gg_kernel(dgrad)", flops, blocks, 1);
 }
 
+void convDownGemm(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* ds, Shape4D* fs, Shape4D* ts, ConvDesc d,
+                  float scaleTargets) {
+  conv_down_impl(derivs, filters, targets, ds, fs, ts, d, scaleTargets, nullptr, 1.0f);
+}
+
 void convDown(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* ds, Shape4D* fs, Shape4D* ts, ConvDesc d,
               float scaleTargets) {
-  convDownGemm(derivs, filters, targets, ds, fs, ts, d, scaleTargets);
+  conv_down_impl(derivs, filters, targets, ds, fs, ts, d, scaleTargets, nullptr, 1.0f);
+}
+
+void convDownMask(cudamat* derivs, cudamat* filters, cudamat* state, cudamat* targets, Shape4D* ds, Shape4D* fs, Shape4D* ts, ConvDesc d,
+                  float scaleTargets, float post_scale) {
+  conv_down_impl(derivs, filters, targets, ds, fs, ts, d, scaleTargets, state, post_scale);
 }
 
 void convOutpGemm(cudamat* images, cudamat* derivs, cudamat* targets, Shape4D* is, Shape4D* ds, Shape4D* ts, ConvDesc d,
@@ -953,7 +981,8 @@ void convOutp(cudamat* images, cudamat* derivs, cudamat* targets, Shape4D* is, S
 //   NT: out(N,F)  = in(N,D)  * W(F,D)^T      -> gg_kernel, A = W   (r-contiguous)
 //   NN: din(N,D)  = dout(N,F)* W(F,D)        -> gg_kernel, A = W   (k-contiguous)
 //   TN: dW(F,D)   = dout(N,F)^T * in(N,D)    -> wg_kernel
-int dotBiasAct(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target, float beta, float alpha, int relu) {
+static int dot_impl(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target, float beta, float alpha, int relu, cudamat* mask,
+                    float post_scale) {
   if (!mat1->on_device || !mat2->on_device || !target->on_device) return ERROR_NOT_ON_DEVICE;
   const int t1 = mat1->is_trans, t2 = mat2->is_trans;
   const int m = t1 ? mat1->size[1] : mat1->size[0], k1 = t1 ? mat1->size[0] : mat1->size[1];
@@ -972,7 +1001,9 @@ int dotBiasAct(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target, flo
     p.DW = 1; p.DP = 1; p.dsy = 1; p.dsx = 1; p.dy0 = 0; p.dx0 = 0;
     p.nblk = divup(m, 128); p.ncols = p.nblk;
     p.scaleTargets = beta; p.relu = relu;
-    const bool base_vec = m % 4 == 0 && aligned16(p.src) && aligned16(p.dst) && aligned16(p.A);
+    if (mask && numel(mask) != numel(target)) return ERROR_INCOMPATIBLE_DIMENSIONS;
+    p.mask = mask ? mask->data_device : nullptr; p.post_scale = post_scale;
+    const bool base_vec = m % 4 == 0 && aligned16(p.src) && aligned16(p.dst) && aligned16(p.A) && aligned16(p.mask);
     t_op = t2 ? "fc_fprop" : "fc_dgrad";
     t_flops = 2.0 * m * (double)n * K;
     if (t2) {   // NT: A[r=f + F*k=d]
@@ -984,7 +1015,7 @@ int dotBiasAct(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target, flo
     return launch_status();
   }
   if (t1 && !t2) {
-    if (bias || relu) return ERROR_UNSUPPORTED;
+    if (bias || relu || mask) return ERROR_UNSUPPORTED;
     // TN: target(m=F, n=D)[f + F*d] = sum_i mat1[i + N*f] * mat2[i + N*d], i over N images
     WGParams p{};
     p.src = mat2->data_device; p.dout = mat1->data_device; p.dst = target->data_device;
@@ -1002,8 +1033,16 @@ int dotBiasAct(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target, flo
   return ERROR_UNSUPPORTED;  // T,T never occurs on the hot path
 }
 
+int dotBiasAct(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target, float beta, float alpha, int relu) {
+  return dot_impl(mat1, mat2, bias, target, beta, alpha, relu, nullptr, 1.0f);
+}
+
+int dotMask(cudamat* mat1, cudamat* mat2, cudamat* state, cudamat* target, float beta, float alpha, float post_scale) {
+  return dot_impl(mat1, mat2, nullptr, target, beta, alpha, 0, state, post_scale);
+}
+
 int dot(cudamat* mat1, cudamat* mat2, cudamat* target, float beta, float alpha) {
-  return dotBiasAct(mat1, mat2, nullptr, target, beta, alpha, 0);
+  return dot_impl(mat1, mat2, nullptr, target, beta, alpha, 0, nullptr, 1.0f);
 }
 
 }  // extern "C"

@@ -79,7 +79,7 @@ __device__ __forceinline__ void cover(int i, int pad, int k, int s, int M, int& 
 // equals this input (all ties count — SURVEY.md fact 9).  AVG: d_in += d_out[o]/|clipped window o|.
 template <bool MAX>
 __global__ void pool_undo_kernel(const float* __restrict__ images, const float* __restrict__ grads, const float* __restrict__ acts,
-                                 float* __restrict__ out, PoolGeo g, float st, bool vec) {
+                                 float* __restrict__ out, PoolGeo g, float st, bool vec, bool relu_mask) {
   const size_t total = (size_t)g.C * g.H * g.W * g.nvec;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int q = (int)(i % g.nvec);
@@ -116,6 +116,10 @@ __global__ void pool_undo_kernel(const float* __restrict__ images, const float* 
         }
       }
     if (st != 0.f) acc = st * ldv(out + t, n, g.N, vec) + acc;
+    if (MAX && relu_mask) {   // fused ReLU' of the layer below: its state IS `images`
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = img[e] > 0.f ? acc[e] : 0.f;
+    }
     stv(out + t, acc, n, g.N, vec);
   }
 }
@@ -305,7 +309,7 @@ void pool_fwd(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, const
 
 template <bool MAX>
 void pool_undo(cudamat* images, cudamat* grads, cudamat* acts, cudamat* targets, Shape4D* in_shape, Shape4D* pooled_shape,
-               const ConvDesc& d, float st) {
+               const ConvDesc& d, float st, bool relu_mask = false) {
   const PoolGeo g = pool_geo(in_shape, pooled_shape, d, targets, grads);
   const bool vec = g.N % 4 == 0 && a16(grads->data_device) && a16(targets->data_device) &&
                    (!MAX || (a16(images->data_device) && a16(acts->data_device)));
@@ -313,7 +317,7 @@ void pool_undo(cudamat* images, cudamat* grads, cudamat* acts, cudamat* targets,
   KernelTimer timer(MAX ? "pool_undo_kernel<max>" : "pool_undo_kernel<avg>", "pool_undo", 0.0,
                     4.0 * g.N * g.C * ((MAX ? 2.0 : 1.0) * g.H * g.W + (MAX ? 2.0 : 1.0) * g.My * g.Mx + (st != 0.f ? (double)g.H * g.W : 0.0)));
   hipLaunchKernelGGL(pool_undo_kernel<MAX>, dim3(grid_for(total)), dim3(256), 0, stream(), MAX ? images->data_device : nullptr,
-                     grads->data_device, MAX ? acts->data_device : nullptr, targets->data_device, g, st, vec);
+                     grads->data_device, MAX ? acts->data_device : nullptr, targets->data_device, g, st, vec, relu_mask);
 }
 
 }  // namespace
@@ -335,6 +339,10 @@ void AvgPool(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, ConvDe
 void MaxPoolUndoGemm(cudamat* images, cudamat* maxGrads, cudamat* maxActs, cudamat* targets, Shape4D* images_shape, Shape4D* maxGrads_shape,
                      ConvDesc d, float scaleTargets) {
   pool_undo<true>(images, maxGrads, maxActs, targets, images_shape, maxGrads_shape, d, scaleTargets);
+}
+void MaxPoolUndoRelu(cudamat* images, cudamat* maxGrads, cudamat* maxActs, cudamat* targets, Shape4D* images_shape,
+                     Shape4D* maxGrads_shape, ConvDesc d, float scaleTargets) {
+  pool_undo<true>(images, maxGrads, maxActs, targets, images_shape, maxGrads_shape, d, scaleTargets, true);
 }
 void MaxPoolUndo(cudamat* images, cudamat* maxGrads, cudamat* maxActs, cudamat* targets, Shape4D* images_shape, Shape4D* maxGrads_shape,
                  ConvDesc d, float scaleTargets) {

@@ -18,6 +18,8 @@ def _divup(x, y):
 
 
 class Edge:
+    can_fuse_mask = False   # ComputeDown(fuse_mask=...) supported
+
     @staticmethod
     def ChooseEdgeClass(edge_config):
         # src/edge.cc:19-66
@@ -303,6 +305,7 @@ class EdgeWithWeight(Edge):
 
 class ConvEdge(EdgeWithWeight):
     """src/conv_edge.{h,cc} (2-D; image_size_t == 1 in all target configs)."""
+    can_fuse_mask = True
 
     def __init__(self, c):
         super().__init__(c)
@@ -390,9 +393,13 @@ class ConvEdge(EdgeWithWeight):
             else:
                 output.AddRowVec(b)
 
-    def ComputeDown(self, deriv_output, input, output, deriv_input, overwrite):
-        # src/conv_edge.cc:172-181
+    def ComputeDown(self, deriv_output, input, output, deriv_input, overwrite, fuse_mask=None):
+        """src/conv_edge.cc:172-181.  ``fuse_mask=post_scale`` additionally applies the source layer's
+        ReLU' (mask = its state, ``input``) and dropout' scale in the kernel epilogue."""
         w = self.tied_edge_.GetWeight() if self.is_tied_ else self.weights_
+        if fuse_mask is not None:
+            Matrix.ConvDownMask(deriv_output, w, input, deriv_input, self.conv_desc_, 0 if overwrite else 1, fuse_mask)
+            return
         Matrix.ConvDown(deriv_output, w, deriv_input, self.conv_desc_, 0 if overwrite else 1)
 
     def ComputeOuter(self, input, deriv_output):
@@ -425,6 +432,7 @@ class ConvEdge(EdgeWithWeight):
 
 class FCEdge(EdgeWithWeight):
     """src/fc_edge.{h,cc}"""
+    can_fuse_mask = True
 
     def _input_size(self):
         return self.image_size_y_ * self.image_size_x_ * self.image_size_t_ * self.num_input_channels_
@@ -470,9 +478,12 @@ class FCEdge(EdgeWithWeight):
         if not self.has_no_bias_:
             output.AddRowVec(self.tied_edge_.GetBias() if self.is_tied_ else self.bias_)
 
-    def ComputeDown(self, deriv_output, input, output, deriv_input, overwrite):
+    def ComputeDown(self, deriv_output, input, output, deriv_input, overwrite, fuse_mask=None):
         # src/fc_edge.cc:63-68
         w = self.tied_edge_.GetWeight() if self.is_tied_ else self.weights_
+        if fuse_mask is not None:
+            Matrix.DotMask(deriv_output, w, input, deriv_input, 0 if overwrite else 1, 1, fuse_mask)
+            return
         Matrix.Dot(deriv_output, w, deriv_input, 0 if overwrite else 1, 1)
 
     def ComputeOuter(self, input, deriv_output):
@@ -514,13 +525,17 @@ class _PoolEdge(Edge):
 
 class MaxPoolEdge(_PoolEdge):
     """src/maxpool_edge.{h,cc}"""
+    can_fuse_mask = True
 
     def ComputeUp(self, input, output, overwrite, train=True, fuse_relu=None):
         if not overwrite:
             raise SystemExit(" In MaxPoolEdge::ComputeUp() : some other layer is writing to this maxpool layer's output as well. Not implemented.")
         Matrix.ConvMaxPool(input, output, self.conv_desc_)
 
-    def ComputeDown(self, deriv_output, input, output, deriv_input, overwrite):
+    def ComputeDown(self, deriv_output, input, output, deriv_input, overwrite, fuse_mask=None):
+        if fuse_mask is not None and fuse_mask == 1.0:
+            Matrix.ConvMaxPoolUndoRelu(input, deriv_output, output, deriv_input, self.conv_desc_, 0 if overwrite else 1)
+            return
         Matrix.ConvMaxPoolUndo(input, deriv_output, output, deriv_input, self.conv_desc_, 0 if overwrite else 1)
 
 

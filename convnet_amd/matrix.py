@@ -329,6 +329,21 @@ class Matrix:
                          ctypes.byref(w.shape_), ctypes.byref(deriv_input.shape_), conv_desc, float(scale_targets))
 
     @staticmethod
+    def ConvDownMask(deriv_output, w, state, deriv_input, conv_desc, scale_targets, post_scale=1.0):
+        """ConvDown with the source layer's ReLU' (and dropout' scale) fused into the epilogue."""
+        lib.convDownMask(deriv_output.GetMat(), w.GetMat(), state.GetMat(), deriv_input.GetMat(), ctypes.byref(deriv_output.shape_),
+                         ctypes.byref(w.shape_), ctypes.byref(deriv_input.shape_), conv_desc, float(scale_targets), float(post_scale))
+
+    @staticmethod
+    def DotMask(a, b, state, c, alpha, beta, post_scale=1.0):
+        _chk(lib.dotMask(a.GetMat(), b.GetMat(), state.GetMat(), c.GetMat(), float(alpha), float(beta), float(post_scale)), "dotMask")
+
+    @staticmethod
+    def ConvMaxPoolUndoRelu(input, deriv_output, output, deriv_input, conv_desc, scale_targets):
+        lib.MaxPoolUndoRelu(input.GetMat(), deriv_output.GetMat(), output.GetMat(), deriv_input.GetMat(),
+                            ctypes.byref(input.shape_), ctypes.byref(deriv_output.shape_), conv_desc, float(scale_targets))
+
+    @staticmethod
     def ConvOutp(input, deriv_output, dw, conv_desc, partial_sum_y, partial_sum_x, scale_targets, scale_outputs):
         lib.convOutpGemm(input.GetMat(), deriv_output.GetMat(), dw.GetMat(), ctypes.byref(input.shape_),
                          ctypes.byref(deriv_output.shape_), ctypes.byref(dw.shape_), conv_desc, float(scale_targets),
@@ -383,6 +398,11 @@ class Matrix:
     def SGDMomentumStep(grad, param, history, l2_decay, gradient_clip, epsilon, momentum):
         _chk(lib.sgd_momentum_step(grad.GetMat(), param.GetMat(), history.GetMat(), float(l2_decay), float(gradient_clip),
                                    float(epsilon), float(momentum)), "sgd step")
+
+    @staticmethod
+    def SGDMomentumStepNormLimit(grad, param, history, l2_decay, gradient_clip, epsilon, momentum, norm, constraint):
+        _chk(lib.sgd_momentum_step_normlimit(grad.GetMat(), param.GetMat(), history.GetMat(), float(l2_decay), float(gradient_clip),
+                                             float(epsilon), float(momentum), float(norm), int(bool(constraint))), "sgd step + norm limit")
 
     # ---- temp / ones pools (src/matrix.cc:633-676) -------------------------------------------------
     @staticmethod

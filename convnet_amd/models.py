@@ -88,8 +88,8 @@ def alexnet(image_size=224, num_classes=1000, dropprob=0.4, grad_check=False):
     s += _conv("hidden3_conv", "hidden4_conv", 3, 1, 1, init_bias=1.0, grad_check=gc)
     s += _conv("hidden4_conv", "hidden5_conv", 3, 1, 0, init_bias=1.0, grad_check=gc)
     s += _pool("hidden5_conv", "hidden5_maxpool", 3, 2, 1)
-    s += _fc("hidden5_maxpool", "hidden6", grad_check=gc) + _fc("hidden6", "hidden7", grad_check=gc)
-    s += _fc("hidden7", "output", grad_check=gc)
+    s += _fc("hidden5_maxpool", "hidden6", norm_limit=4, grad_check=gc) + _fc("hidden6", "hidden7", norm_limit=4, grad_check=gc)
+    s += _fc("hidden7", "output", norm_limit=4, grad_check=gc)
     return s
 
 

@@ -107,8 +107,16 @@ class SGDOptimizer(Optimizer):
         if self.step_ >= self.start_optimization_after_:
             epsilon = self.GetDecayedEpsilon()
             if self.fused and not self.nesterov_momentum_:
-                Matrix.SGDMomentumStep(gradient, parameter, self.gradient_history_, self.l2_decay_,
-                                       self.gradient_clip_, epsilon, self.GetMomentum())
+                if self.weight_norm_constraint_ > 0 or self.weight_norm_limit_ > 0:
+                    con = self.weight_norm_constraint_ > 0
+                    Matrix.SGDMomentumStepNormLimit(gradient, parameter, self.gradient_history_, self.l2_decay_, self.gradient_clip_,
+                                                    epsilon, self.GetMomentum(),
+                                                    self.weight_norm_constraint_ if con else self.weight_norm_limit_, con)
+                else:
+                    Matrix.SGDMomentumStep(gradient, parameter, self.gradient_history_, self.l2_decay_,
+                                           self.gradient_clip_, epsilon, self.GetMomentum())
+                self.step_ += 1
+                return
             else:
                 if self.l2_decay_ > 0:
                     gradient.Add(parameter, self.l2_decay_)

@@ -233,9 +233,25 @@ int dotBiasAct(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target, flo
                int relu);
 int sgd_momentum_step(cudamat* grad, cudamat* param, cudamat* history, float l2_decay,
                       float gradient_clip, float epsilon, float momentum);
+int sgd_momentum_step_normlimit(cudamat* grad, cudamat* param, cudamat* history, float l2_decay,
+                                float gradient_clip, float epsilon, float momentum, float norm,
+                                int constraint);   /* + ApplyConstraints (src/optimizer.cc:75-81), axis=1 */
 int softmax_ce_grad_correct(cudamat* logits, cudamat* labels, cudamat* probs, cudamat* deriv,
                             cudamat* correct_accum, float deriv_scale);
 int relu_dropout(rnd_struct* rnd_state, cudamat* mat, float dropprob, float scale);
+/* Backward fusions: the producing kernel applies the consumer layer's ReLU' (and dropout' scale) in
+ * its epilogue instead of a separate read-modify-write pass over the derivative
+ * (Layer::ApplyDerivativeofDropout + ReLULayer::ApplyDerivativeOfActivation, src/layer.cc:399-413,556-558):
+ *   targets = (state > 0) ? post_scale * (scaleTargets*targets + op(...)) : 0.
+ * Valid when the layer has a single outgoing edge (src/convnet.cc:390-404 applies them after ALL edges). */
+void convDownMask(cudamat* derivs, cudamat* filters, cudamat* state, cudamat* targets,
+                  Shape4D* derivs_shape, Shape4D* filters_shape, Shape4D* targets_shape,
+                  ConvDesc conv_desc, float scaleTargets, float post_scale);
+int dotMask(cudamat* mat1, cudamat* mat2, cudamat* state, cudamat* target, float beta, float alpha,
+            float post_scale);
+void MaxPoolUndoRelu(cudamat* images, cudamat* maxGrads, cudamat* maxActs, cudamat* targets,
+                     Shape4D* images_shape, Shape4D* maxGrads_shape, ConvDesc conv_desc,
+                     float scaleTargets);
 
 /* ---- introspection for the roofline report: flops of the last MFMA launch family ----------------- */
 typedef struct ConvnetHipKernelInfo {

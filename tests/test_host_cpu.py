@@ -1,0 +1,94 @@
+"""CPU: host logic that needs no GPU — the pbtxt reader, the model zoo against the reference's own
+model files (when mounted), graph building / sizing / parameter layout, optimizer schedules."""
+import math
+import os
+
+import pytest
+
+from convnet_amd import models, pbtxt
+from convnet_amd.convnet import ConvNet
+from convnet_amd.optimizer import SGDOptimizer
+
+REF = "/root/reference/examples"
+
+
+def test_pbtxt_reader_defaults_presence_and_errors():
+    m = pbtxt.parse('name: "x"  seed: 7 # comment\nlayer { name: "a" num_channels: 3 }\n'
+                    'edge { source: "a" dest: "b" edge_type: CONVOLUTIONAL kernel_size: 3 grad_check_epsilon: 0.01 grad_check_epsilon: 1e-3\n'
+                    '  weight_optimizer { epsilon: 0.5 } }')
+    assert m.name == "x" and m.seed == 7 and m.max_iter == -1
+    e = m.edge[0]
+    assert e.edge_type == "CONVOLUTIONAL" and e.kernel_size == 3 and e.stride == 1 and e.padding == 0
+    assert e.has_kernel_size() and not e.has_kernel_size_y() and e.kernel_size_y == 0
+    assert e.grad_check_epsilon == [0.01, 0.001]
+    assert e.weight_optimizer.epsilon == 0.5 and e.weight_optimizer.final_momentum == 0.0
+    assert not e.has_bias_optimizer() and e.bias_optimizer.gradient_clip == -1.0
+    assert m.layer[0].activation == "LINEAR" and m.layer[0].loss_function == "CROSS_ENTROPY_MULTINOMIAL"
+    with pytest.raises(ValueError):
+        pbtxt.parse('name: "x" bogus_field: 3')
+    d = pbtxt.Optimizer()
+    d.epsilon = 0.1
+    d.l2_decay = 0.5
+    o = d.copy()
+    o.MergeFrom(e.weight_optimizer)      # default-optimizer merge, src/convnet.cc:36-50
+    assert o.epsilon == 0.5 and o.l2_decay == 0.5
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted")
+@pytest.mark.parametrize("gen,path", [(models.alexnet, "imagenet/CLS_net_20140621074703.pbtxt"), (models.mnist_conv, "mnist-conv/net.pbtxt")])
+def test_generated_models_equal_reference_pbtxt(gen, path):
+    ref, mine = pbtxt.read(os.path.join(REF, path)), pbtxt.parse(gen())
+
+    def sig(m):
+        out = [(l.name, l.num_channels, l.activation, l.dropprob, l.image_size_y, l.image_size_x) for l in m.layer]
+        for e in m.edge:
+            w, b = e.weight_optimizer, e.bias_optimizer
+            out.append((e.source, e.dest, e.edge_type, e.kernel_size, e.stride, e.padding, e.shared_bias, e.initialization, e.init_wt,
+                        e.init_bias, w.epsilon, w.final_momentum, w.momentum_transition_timescale, w.l2_decay, w.weight_norm_limit,
+                        b.epsilon, b.final_momentum, b.l2_decay, e.add_scale, e.pow_scale, e.frac_of_filters_response_norm))
+        return out
+    assert sig(ref) == sig(mine)
+
+
+def test_alexnet_graph_sizes_params_and_work_match_the_survey():
+    net = ConvNet(models.alexnet())
+    sizes = {l.GetName(): (l.GetSizeY(), l.GetNumChannels()) for l in net.layers_}
+    assert sizes["hidden1_conv"] == (110, 96) and sizes["hidden1_maxpool"] == (55, 96) and sizes["hidden2_conv"] == (26, 256)
+    assert sizes["hidden2_rnorm"] == (13, 256) and sizes["hidden5_conv"] == (11, 256) and sizes["hidden5_maxpool"] == (6, 256)
+    assert [l.GetName() for l in net.layers_][0] == "input" and net.layers_[-1].GetName() == "output"
+    assert sum(e.GetParameterMemoryRequirement() for e in net.edges_) == 62357608
+    fwd, train = models.count_macs(net)
+    assert fwd == 1125565568 and train == 3205941504
+    rn = net.GetEdgeByName("hidden1_maxpool:hidden1_rnorm")
+    assert rn.num_filters_response_norm_ == 24
+    d = net.GetEdgeByName("input:hidden1_conv").conv_desc_
+    assert (d.padding_y, d.padding_x, d.stride_y, d.kernel_size_x) == (-1, -1, 2, 7)           # stored negated
+
+
+def test_mnist_and_vgg_graphs():
+    net = ConvNet(models.mnist_conv())
+    assert [(l.GetSizeY(), l.GetNumChannels()) for l in net.layers_] == [(28, 1), (25, 48), (11, 48), (8, 128), (3, 128), (1, 10)]
+    fwd, _ = models.count_macs(net)
+    assert fwd == 480000 + 6291456 + 11520
+    v = ConvNet(models.vgg())
+    assert v.GetLayerByName("pool5").GetSizeY() == 7 and len([e for e in v.edges_ if e.GetParameterMemoryRequirement()]) == 16
+
+
+def test_sgd_schedules():
+    c = pbtxt.Optimizer()
+    c.epsilon, c.initial_momentum, c.final_momentum, c.momentum_transition_timescale = 0.01, 0.5, 0.9, 2000
+    o = SGDOptimizer.__new__(SGDOptimizer)
+    from convnet_amd.optimizer import Optimizer
+    Optimizer.__init__(o, c)
+    o.initial_momentum_, o.final_momentum_, o.momentum_transition_timescale_ = 0.5, 0.9, 2000
+    o.step_ = 0
+    assert o.GetMomentum() == 0.5
+    o.step_ = 2000
+    assert abs(o.GetMomentum() - (0.5 + 0.4 * (1 - math.exp(-1)))) < 1e-12                    # src/optimizer.cc:158-165
+    c2 = pbtxt.Optimizer()
+    c2.epsilon, c2.epsilon_decay, c2.epsilon_decay_timescale, c2.minimum_epsilon = 1.0, "INVERSE_T", 10, 0.2
+    Optimizer.__init__(o, c2)
+    o.step_ = 10
+    assert o.GetDecayedEpsilon() == 0.5
+    o.step_ = 1000
+    assert o.GetDecayedEpsilon() == 0.2

@@ -1,0 +1,163 @@
+"""GPU: whole-net tests through the ConvNet driver.
+ * Fprop(false) activations of a small AlexNet-shaped net == the CPU oracle run layer by layer on the
+   same weights and inputs (tolerance: the reference's 1e-4, py/test_conv.py:382-392).
+ * fused entry points == the reference's unfused Matrix-call sequence (same net, same data).
+ * run_grad_check equivalent passes (mean scaled diff < 0.01, src/grad_check.cc:61) on mnist-conv,
+   LeNet-5-class (avg-pool) and an AlexNet-shaped net with response norm.
+ * one SGD step leaves parameters equal between fused/unfused; training reduces the loss.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402
+from oracle import Geom  # noqa: E402
+from golden_cases import rel_err  # noqa: E402
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available()
+    from convnet_amd.matrix import Matrix
+    Matrix.SetupCUDADevice(0)
+    return Matrix
+
+
+def small_alexnet(dropprob=0.0, grad_check=False):
+    """AlexNet topology (conv-pool-rnorm x2, conv x3, pool, fc x3) at 35x35 input / thin channels."""
+    from convnet_amd import models
+    gc = models._gc(grad_check, 6)
+    s = models._header("tiny_alex")
+    L, C, P, R, F = models._layer, models._conv, models._pool, models._rnorm, models._fc
+    s += L("input", 3, size=35)
+    s += L("c1", 16, "RECTIFIED_LINEAR") + L("p1", 16) + L("r1", 16, "RECTIFIED_LINEAR")
+    s += L("c2", 24, "RECTIFIED_LINEAR") + L("p2", 24) + L("r2", 24, "RECTIFIED_LINEAR")
+    s += L("c3", 32, "RECTIFIED_LINEAR") + L("c4", 32, "RECTIFIED_LINEAR") + L("c5", 24, "RECTIFIED_LINEAR") + L("p5", 24)
+    s += L("f6", 48, "RECTIFIED_LINEAR", dropprob) + L("f7", 40, "RECTIFIED_LINEAR", dropprob) + L("output", 10, "SOFTMAX")
+    s += C("input", "c1", 5, 2, 1, grad_check=gc) + P("c1", "p1", 3, 2, 1) + R("p1", "r1", 0.05, 0.75, 0.5)
+    s += C("r1", "c2", 3, 1, 0, init_bias=1.0, grad_check=gc) + P("c2", "p2", 3, 2, 1) + R("p2", "r2", 0.05, 0.75, 0.25)
+    s += C("r2", "c3", 3, 1, 1, grad_check=gc) + C("c3", "c4", 3, 1, 1, init_bias=1.0, grad_check=gc) + C("c4", "c5", 3, 1, 0, init_bias=1.0, grad_check=gc)
+    s += P("c5", "p5", 3, 2, 1)
+    s += F("p5", "f6", grad_check=gc) + F("f6", "f7", grad_check=gc) + F("f7", "output", grad_check=gc)
+    return s
+
+
+def build(text, batch, fused, seed_data=5, cls=None):
+    from convnet_amd.convnet import ConvNet
+    from convnet_amd.datahandler import SyntheticDataHandler
+    net = (cls or ConvNet)(text, fused=fused)
+    net.SetBatchsize(batch)
+    data = SyntheticDataHandler(net, batch, seed=seed_data, num_batches=1)
+    net.SetupDataset(data)
+    net.AllocateMemory(False)
+    return net
+
+
+def copy_params(src, dst):
+    dst.parameters_.Set(src.parameters_)
+
+
+def test_fprop_activations_match_cpu_oracle_layer_by_layer(gpu):
+    from convnet_amd.edge import ConvEdge, FCEdge, MaxPoolEdge, ResponseNormEdge
+    N = 8
+    net = build(small_alexnet(), N, fused=False)
+    for l in net.layers_:
+        l.ResetAddOrOverwrite()
+    net.GetBatch(net.train_dataset_)
+    net.Fprop(False)
+    # replay on the oracle, edge by edge, with the device's parameters
+    acts = {net.input_layers_[0].GetName(): net.input_layers_[0].GetState().ToNumpy()}
+    for l in net.layers_:
+        if l.IsInput():
+            continue
+        e = l.incoming_edge_[0]
+        src = e.GetSource()
+        x = acts[src.GetName()]
+        C, H, W = src.GetNumChannels(), src.GetSizeY(), src.GetSizeX()
+        if isinstance(e, ConvEdge):
+            d = e.conv_desc_
+            g = Geom(N, C, H, W, d.num_output_channels, d.kernel_size_y, d.kernel_size_x, d.stride_y, d.stride_x, -d.padding_y, -d.padding_x)
+            w = e.GetWeight().ToNumpy().reshape(g.filt_shape())
+            y = oracle.port.conv_up(g, x.reshape(g.in_shape()), w)
+            y = oracle.port.add_row_vec(y.reshape(g.F, -1), e.GetBias().ToNumpy().reshape(-1)).reshape(-1)
+        elif isinstance(e, MaxPoolEdge):
+            d = e.conv_desc_
+            g = Geom(N, C, H, W, C, d.kernel_size_y, d.kernel_size_x, d.stride_y, d.stride_x, -d.padding_y, -d.padding_x)
+            y = oracle.port.max_pool(g, x.reshape(g.in_shape())).reshape(-1)
+        elif isinstance(e, ResponseNormEdge):
+            y = oracle.port.rnorm(x.reshape(C, H, W, N), e.num_filters_response_norm_, e.add_scale_, e.pow_scale_, e.blocked_).reshape(-1)
+        elif isinstance(e, FCEdge):
+            Fo = l.GetNumChannels()
+            w = e.GetWeight().ToNumpy()             # (D, F) numpy view of (F, D) col-major
+            y = oracle.port.dot(np.ascontiguousarray(x.reshape(-1, N)), w, np.zeros((Fo, N), np.float32), 0.0, 1.0, False, True)
+            y = oracle.port.add_row_vec(y, e.GetBias().ToNumpy().reshape(-1)).reshape(-1)
+        if l.is_relu:
+            y = oracle.port.lower_bound(y, 0.0)
+        if l.IsOutput():
+            y = oracle.port.softmax_row_major(y.reshape(l.GetNumChannels(), N)).reshape(-1)
+        acts[l.GetName()] = y
+        got = l.GetState().ToNumpy().reshape(-1)
+        assert rel_err(got, y) < TOL, (l.GetName(), rel_err(got, y))
+
+
+@pytest.mark.parametrize("which", ["tiny_alex", "mnist_conv", "lenet5"])
+def test_fused_equals_unfused_forward_backward_and_update(gpu, which):
+    from convnet_amd import models
+    text = {"tiny_alex": small_alexnet(), "mnist_conv": models.mnist_conv(), "lenet5": models.lenet5()}[which]
+    N = 32
+    a, b = build(text, N, fused=False), build(text, N, fused=True)
+    copy_params(a, b)
+    for net in (a, b):
+        for l in net.layers_:
+            l.ResetAddOrOverwrite()
+        net.GetBatch(net.train_dataset_)
+        net.Fprop(True)       # no dropout in these nets: deterministic
+        net.ComputeDeriv()
+        net.Bprop()
+    for la, lb in zip(a.layers_, b.layers_):
+        assert rel_err(la.GetState().ToNumpy(), lb.GetState().ToNumpy()) < 1e-5, la.GetName()
+    ga, gb = a.grad_parameters_.ToNumpy(), b.grad_parameters_.ToNumpy()
+    assert rel_err(ga, gb) < 1e-5
+    # fused mode counted correct predictions on device; unfused computes them per step on the host
+    assert abs(b.ReadCorrectCount() - a.GetLoss()[0]) < 0.5
+    a.UpdateWeights()
+    b.UpdateWeights()
+    assert rel_err(a.parameters_.ToNumpy(), b.parameters_.ToNumpy()) < 1e-6
+
+
+@pytest.mark.parametrize("which,batch", [("mnist_conv", 16), ("lenet5", 16), ("tiny_alex", 8)])
+def test_grad_check_passes(gpu, which, batch):
+    """run_grad_check parity gate: every flagged edge's weights and bias pass (src/grad_check.cc:61)."""
+    from convnet_amd import models
+    from convnet_amd.grad_check import GradChecker
+    text = {"tiny_alex": small_alexnet(grad_check=True), "mnist_conv": models.mnist_conv(grad_check=True),
+            "lenet5": models.lenet5(grad_check=True)}[which]
+    net = build(text, batch, fused=False, cls=GradChecker)
+    res = net.Run()
+    assert len(res) >= 3
+    failed = [(name, what) for name, r in res.items() for what in ("weights", "bias") if not r[what][0]]
+    assert not failed, failed
+
+
+def test_training_reduces_loss_and_dropout_net_runs(gpu):
+    N = 64
+    net = build(small_alexnet(dropprob=0.4), N, fused=True)
+    # make the synthetic task learnable: labels = argmax of a fixed random projection of the input
+    x = net.train_dataset_.batches_[0]["input"].ToNumpy()
+    proj = np.random.default_rng(3).standard_normal((10, x.shape[0])).astype(np.float32)
+    net.train_dataset_.batches_[0]["output"].FromNumpy((proj @ x).argmax(0).astype(np.float32))
+    first = None
+    for it in range(60):
+        net.TrainOneBatch()
+        if it == 0:
+            first = net.ReadCorrectCount()
+    net.ReadCorrectCount()
+    for _ in range(5):
+        net.TrainOneBatch()
+    last = net.ReadCorrectCount() / 5
+    assert last > first + 5, (first, last)
+    assert np.isfinite(net.parameters_.ToNumpy()).all()
