@@ -64,6 +64,11 @@ def _load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    # torch must be imported BEFORE the dlopen: the library's libamdhip64 dependency then resolves (by
+    # SONAME) to the HIP runtime torch already loaded, so both share ONE runtime — required, because torch
+    # streams and device pointers are handed straight to the library.  Loading ours first pulls in
+    # /opt/rocm's copy and hipSetDevice later fails with two runtimes in the process.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     P, F, I = ctypes.POINTER, ctypes.c_float, ctypes.c_int
     M, S = P(cudamat), P(Shape4D)

@@ -15,6 +15,7 @@ hipStream_t stream();
 // Grow-only scratch arena.  Returns a device pointer valid until the next call that asks for more
 // than the current capacity (growth synchronises the stream first, so in-flight users stay valid).
 void* workspace(size_t bytes);
+void* workspace_aux(size_t bytes);   // independent second arena (dgrad filter images)
 // 256 bytes of device zeros (allocated once): where branch-free kernels point out-of-range loads.
 const float* zero_page();
 void set_last_error(const char* msg);

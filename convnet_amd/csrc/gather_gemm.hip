@@ -19,6 +19,7 @@
 // contiguous dimension of every activation, so it is mapped to the D *column* (lane) dimension:
 // loads of 4 consecutive images per lane are one ds_read_b128 / global dwordx4 and stores are
 // 512 contiguous bytes per half-wave.  64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak (fp32 matrix).
+#include <cmath>
 #include <string>
 
 #include "common.h"
@@ -699,12 +700,25 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   p.zero = zero_page();
   const int tiles = p.row_tiles * p.col_tiles;
   const int kchunks = divup(p.K, BK);
+  // Split-K factor by wave quantisation: every block of a launch takes the same time, so a grid of b
+  // blocks on `slots` resident-block slots runs ceil(b/slots) rounds and wastes the empty part of the
+  // last one (338 tiles on 512 slots = 66 % busy; 3 K-splits = 1014 blocks = 99 %).  Pick the split with
+  // the best estimated time = rounds * (work per block) + slab-reduce traffic; needs a launch that owns
+  // the whole destination (dst_elems > 0).
   int splits = 1;
-  if (dst_elems > 0 && kchunks >= 32 && tiles < kTargetBlocks / 2) {
-    splits = kTargetBlocks / tiles;
-    if (splits > kchunks / 16) splits = kchunks / 16;
-    if (splits > 32) splits = 32;
-    if (splits < 1) splits = 1;
+  if (dst_elems > 0 && kchunks >= 16) {
+    const double slots = kTargetBlocks;
+    const double flops = 2.0 * ROWS * (WC * 128.0) * (double)p.K;           // per tile, all K
+    double best_t = 1e30;
+    for (int sp = 1; sp <= 16 && kchunks / sp >= 8; ++sp) {
+      const double rounds = std::ceil(tiles * (double)sp / slots);
+      double t = rounds * (flops / sp) / (2 * 64.0 * 4 * 2.2e9 * 0.8);     // block time on half a CU at 80 %
+      if (sp > 1) t += sizeof(float) * (double)dst_elems * (2.0 * sp + 1) / 4.0e12 + 4e-6;
+      if (t < best_t * 0.97) {
+        best_t = t;
+        splits = sp;
+      }
+    }
   }
   p.chunks_per_split = kchunks > 0 ? divup(kchunks, splits) : 1;
   splits = kchunks > 0 ? divup(kchunks, p.chunks_per_split) : 1;
@@ -738,18 +752,9 @@ void gg_run(GGParams& p, bool vec, size_t dst_elems) {
   // pick the row tile (128/64/32) that pads the fewest rows; ties go to the larger tile.  (The 96-row
   // 6-wave config measured 68 TFLOP/s vs 106 for the 128-row one, so 96-row problems — conv1 fprop,
   // conv2 dgrad — run 25 % padded on the 128-row kernel: 80 effective TFLOP/s.)
-  int best = 128, best_pad = divup(p.R, 128) * 128;
-  const int cands[2] = {64, 32};
-  for (int c : cands) {
-    const int pad = divup(p.R, c) * c;
-    if (pad < best_pad) {
-      best = c;
-      best_pad = pad;
-    }
-  }
+  const int best = p.R > 64 ? 128 : (p.R > 32 ? 64 : 32);
   switch (best) {
     case 128: gg_launch_cfg<2, 2, 2, AK>(p, vec, dst_elems); break;   // 128 rows x 2 wave-columns
-    case 96: gg_launch_cfg<3, 2, 1, AK>(p, vec, dst_elems); break;    //  96 rows x 2 (6 waves)
     case 64: gg_launch_cfg<2, 2, 1, AK>(p, vec, dst_elems); break;    //  64 rows x 2
     default: gg_launch_cfg<1, 4, 1, AK>(p, vec, dst_elems); break;    //  32 rows x 4
   }
@@ -764,14 +769,17 @@ void wg_launch_cfg(WGParams& p, bool vec) {
   p.zero = zero_page();
   const int tiles = p.k_tiles * p.f_tiles;
   const size_t total = (size_t)p.K * p.F;
+  // one full round of resident blocks (2 per CU): floor, not ceil — 568 blocks on 512 slots take two
+  // rounds and leave the chip half empty (measured: 1.05 waves/SIMD, 46 % MFMA busy).
   int splits = 1;
   if (tiles < kTargetBlocks) {
-    splits = divup(kTargetBlocks, tiles);
+    splits = kTargetBlocks / tiles;
     const int max_by_len = p.chunks_total / 16 > 0 ? p.chunks_total / 16 : 1;
     if (splits > max_by_len) splits = max_by_len;
     const size_t max_by_bytes = (size_t(256) << 20) / (total * sizeof(float)) + 1;
     if ((size_t)splits > max_by_bytes) splits = (int)max_by_bytes;
     if (splits > 1024) splits = 1024;
+    if (splits < 1) splits = 1;
   }
   p.chunks_per_split = divup(p.chunks_total, splits);
   splits = divup(p.chunks_total, p.chunks_per_split);
@@ -891,7 +899,7 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
   if (mask) CHIP_REQUIRE(numel(mask) == numel(targets));
   // one launch per stride class (cy,cx): input rows iy with (iy - pad) % sy == cy share the tap set
   // ky = cy + sy*a; their sources are oy = (iy - pad - cy)/sy - a  (pad = ConvDesc padding, <= 0).
-  float* wt = static_cast<float*>(workspace(sizeof(float) * (size_t)g.C * g.F * g.Ky * g.Kx + 256 * g.sy * g.sx));
+  float* wt = static_cast<float*>(workspace_aux(sizeof(float) * (size_t)g.C * g.F * g.Ky * g.Kx + 256 * g.sy * g.sx));
   size_t woff = 0;
   double flops = 0;
   int blocks = 0;
@@ -930,7 +938,9 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
       const bool vec = g.N % 4 == 0 && g.C % 4 == 0 && aligned16(p.src) && aligned16(p.dst) && aligned16(p.mask);
       t_op = "conv_dgrad";
       t_flops = 2.0 * g.N * p.G * (double)g.C * p.K;
-      gg_run<false>(p, vec, 0);
+      // a stride-1 convolution has a single class that owns every input pixel: split-K is legal there
+      const bool whole = g.sy == 1 && g.sx == 1 && GY == g.H && GX == g.W;
+      gg_run<false>(p, vec, whole ? (size_t)g.N * g.H * g.W * g.C : 0);
       flops += 2.0 * g.N * p.G * (double)g.C * p.K;
       blocks += p.row_tiles * p.col_tiles;
     }

@@ -30,6 +30,19 @@ void* workspace(size_t bytes) {
   return g_ws;
 }
 
+// Second, independent arena: the dgrad filter images live here while the same call may take
+// split-K slabs from workspace() (two simultaneous users must not share one base pointer).
+void* workspace_aux(size_t bytes) {
+  static void* ws = nullptr;
+  static size_t cap = 0;
+  if (bytes <= cap) return ws;
+  CHIP_CHECK(hipStreamSynchronize(g_stream));
+  if (ws) CHIP_CHECK(hipFree(ws));
+  cap = ((bytes + (size_t(1) << 20)) >> 20) << 20;
+  CHIP_CHECK(hipMalloc(&ws, cap));
+  return ws;
+}
+
 const float* zero_page() {
   static float* z = nullptr;
   if (!z) {

@@ -1,0 +1,93 @@
+"""Whole-net forward/backward on the CPU oracle, driven by a built ConvNet's graph and parameters
+(sequential nets: every layer has one incoming edge).  Follows ConvNet::Fprop/Bprop order
+(src/convnet.cc:377-405): per layer, ComputeOuter then ComputeDown of its outgoing edge, then
+dropout' (none here) and activation'."""
+import numpy as np
+
+import oracle
+from oracle import Geom
+
+
+def _geom(e, src, N, pool=False):
+    d = e.conv_desc_
+    C, H, W = src.GetNumChannels(), src.GetSizeY(), src.GetSizeX()
+    return Geom(N, C, H, W, C if pool else d.num_output_channels, d.kernel_size_y, d.kernel_size_x, d.stride_y, d.stride_x,
+                -d.padding_y, -d.padding_x)
+
+
+def forward_backward(net, x, labels, impl=None):
+    from convnet_amd.edge import AvgPoolEdge, ConvEdge, FCEdge, MaxPoolEdge, ResponseNormEdge
+    O = impl or oracle.port
+    N = labels.size
+    acts = {net.input_layers_[0].GetName(): np.ascontiguousarray(x.reshape(-1))}
+    pre = {}
+    for l in net.layers_:
+        if l.IsInput():
+            continue
+        e = l.incoming_edge_[0]
+        src = e.GetSource()
+        a = acts[src.GetName()]
+        if isinstance(e, ConvEdge):
+            g = _geom(e, src, N)
+            y = O.conv_up(g, a.reshape(g.in_shape()), e.GetWeight().ToNumpy().reshape(g.filt_shape()))
+            y = O.add_row_vec(y.reshape(g.F, -1), e.GetBias().ToNumpy().reshape(-1)).reshape(-1)
+        elif isinstance(e, MaxPoolEdge):
+            g = _geom(e, src, N, True)
+            y = O.max_pool(g, a.reshape(g.in_shape())).reshape(-1)
+        elif isinstance(e, AvgPoolEdge):
+            g = _geom(e, src, N, True)
+            y = O.avg_pool(g, a.reshape(g.in_shape())).reshape(-1)
+        elif isinstance(e, ResponseNormEdge):
+            C = src.GetNumChannels()
+            y = O.rnorm(a.reshape(C, -1, 1, N), e.num_filters_response_norm_, e.add_scale_, e.pow_scale_, e.blocked_).reshape(-1)
+        elif isinstance(e, FCEdge):
+            Fo = l.GetNumChannels()
+            y = O.dot(np.ascontiguousarray(a.reshape(-1, N)), e.GetWeight().ToNumpy(), np.zeros((Fo, N), np.float32), 0.0, 1.0, False, True)
+            y = O.add_row_vec(y, e.GetBias().ToNumpy().reshape(-1)).reshape(-1)
+        else:
+            raise NotImplementedError(type(e))
+        if l.is_relu:
+            y = O.lower_bound(y, 0.0)
+        if l.IsOutput():
+            y = O.softmax_row_major(y.reshape(l.GetNumChannels(), N)).reshape(-1)
+        acts[l.GetName()] = y
+    out = net.output_layers_[0]
+    derivs = {out.GetName(): O.softmax_grad_row_major(acts[out.GetName()].reshape(out.GetNumChannels(), N), labels).reshape(-1)}
+    grads = {}
+    for l in reversed(net.layers_):
+        if l.IsOutput():
+            continue
+        e = l.outgoing_edge_[0]
+        dst = e.GetDest()
+        a, dy, yact = acts[l.GetName()], derivs[dst.GetName()], acts[dst.GetName()]
+        dx = None
+        if isinstance(e, ConvEdge):
+            g = _geom(e, l, N)
+            dw = O.conv_outp(g, a.reshape(g.in_shape()), dy.reshape(g.out_shape()), None, 0.0, e.scale_gradients_ / N)
+            db = O.sum_by_axis(np.ascontiguousarray(dy.reshape(g.F, -1)), np.zeros(g.F, np.float32), 0, e.scale_gradients_ / N, 0.0)
+            grads[e.GetName()] = (dw.reshape(-1), db)
+            if not l.IsInput():
+                dx = O.conv_down(g, dy.reshape(g.out_shape()), e.GetWeight().ToNumpy().reshape(g.filt_shape())).reshape(-1)
+        elif isinstance(e, FCEdge):
+            D, Fo = a.size // N, dst.GetNumChannels()
+            a2, dy2 = np.ascontiguousarray(a.reshape(D, N)), np.ascontiguousarray(dy.reshape(Fo, N))
+            dw = O.dot(dy2, a2, np.zeros((D, Fo), np.float32), 0.0, e.scale_gradients_ / N, True, False)
+            db = O.sum_by_axis(dy2, np.zeros(Fo, np.float32), 0, e.scale_gradients_ / N, 0.0)
+            grads[e.GetName()] = (dw.reshape(-1), db)
+            if not l.IsInput():
+                dx = O.dot(dy2, e.GetWeight().ToNumpy(), np.zeros((D, N), np.float32), 0.0, 1.0).reshape(-1)
+        elif isinstance(e, MaxPoolEdge):
+            g = _geom(e, l, N, True)
+            dx = O.max_pool_undo(g, a.reshape(g.in_shape()), dy.reshape(g.pooled_shape()), yact.reshape(g.pooled_shape())).reshape(-1)
+        elif isinstance(e, AvgPoolEdge):
+            g = _geom(e, l, N, True)
+            dx = O.avg_pool_undo(g, dy.reshape(g.pooled_shape())).reshape(-1)
+        elif isinstance(e, ResponseNormEdge):
+            C = l.GetNumChannels()
+            dx = O.rnorm_undo(dy.reshape(C, -1, 1, N), a.reshape(C, -1, 1, N), e.num_filters_response_norm_, e.add_scale_, e.pow_scale_,
+                              e.blocked_).reshape(-1)
+        if dx is not None and not l.IsInput():
+            if l.is_relu:
+                dx = O.relu_deriv(dx, a)
+            derivs[l.GetName()] = dx
+    return acts, derivs, grads
