@@ -115,7 +115,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=8.0)
+    ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange path even with 1 rank (self-test)")
     args = ap.parse_args()
+
+    # RCCL prints a version banner on the C-level stdout at communicator creation; keep the real stdout
+    # for the single JSON line and send everything else (python and C) to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    result_line = ""
 
     import torch
     import torch.distributed as dist
@@ -131,8 +139,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
     Matrix.SetupCUDADevice(local_rank)
     exchange = None
-    if world > 1:
+    if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         from convnet_amd.data_parallel import GradientExchange
         exchange = GradientExchange(bucket_bytes=int(args.bucket_mb * (1 << 20)), overlap=not args.no_overlap)
@@ -147,7 +156,7 @@ def main():
     step_flops = 2.0 * train_macs * args.batch
 
     def sync_all():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -164,7 +173,7 @@ def main():
     prof = _lib.profile_report()
 
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -217,9 +226,12 @@ def main():
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline is a report, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
-        print(json.dumps(out))
-    if world > 1:
+        result_line = json.dumps(out)
+    if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(real_stdout, (result_line + "\n").encode())   # the ONE line on the real stdout
 
 
 if __name__ == "__main__":

@@ -193,7 +193,7 @@ class ConvNet:
         if self.is_root_ or self.exchange_ is None:
             for e in self.edges_:
                 e.Initialize()
-        if self.num_processes_ > 1 and self.exchange_ is not None:
+        if self.exchange_ is not None:
             self.exchange_.Broadcast(self.parameters_)   # src/convnet.cc:309
             if not fprop_only:
                 self.exchange_.Register(self)

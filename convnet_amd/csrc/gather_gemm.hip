@@ -69,15 +69,19 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
   return (b & 7) * per + (b >> 3);
 }
 
-template <int WR, int WC, int MT, bool A_KCONTIG, bool VEC>
+// CW = images per wave-column (128: 4 interleaved 32-image MFMA column tiles per wave, ds_read_b128;
+// 64: 2 tiles, ds_read_b64 — used with MT=3 so a 96-row problem (conv1 fprop, conv2 dgrad) fills its tile).
+template <int WR, int WC, int MT, int CW, bool A_KCONTIG, bool VEC>
 __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg_kernel(const GGParams p) {
   constexpr int NT = WR * WC * 64;
+  constexpr int NTC = CW / 32, CW4 = CW / 4;
+  using fvec = __attribute__((ext_vector_type(NTC))) float;
   constexpr int ROWS = WR * MT * 32;
   constexpr int APITCH = A_KCONTIG ? (BK + 4) : ROWS;
   constexpr int A_STAGE = A_KCONTIG ? ROWS * APITCH : BK * ROWS;
-  constexpr int B_STAGE = WC * BK * 128;
+  constexpr int B_STAGE = WC * BK * CW;
   constexpr int NA = ((A_KCONTIG ? ROWS * (BK / 4) : BK * (ROWS / 4)) + NT - 1) / NT;
-  constexpr int NB = (WC * BK * 32 + NT - 1) / NT;
+  constexpr int NB = (WC * BK * CW4 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][A_STAGE]
   float* Bs = smem + 2 * A_STAGE;   // [2][B_STAGE]
@@ -102,17 +106,17 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
 #pragma unroll
   for (int it = 0; it < NB; ++it) {
     const int idx = tid + it * NT;
-    const int wcol = idx / (BK * 32), krow = (idx / 32) % BK, c4 = idx % 32;
+    const int wcol = idx / (BK * CW4), krow = (idx / CW4) % BK, c4 = idx % CW4;
     const int colid = col_tile * WC + wcol;
-    const bool ok = idx < WC * BK * 32 && colid < p.ncols;
+    const bool ok = idx < WC * BK * CW4 && colid < p.ncols;
     const int m = ok ? colid / p.nblk : 0, blk = ok ? colid % p.nblk : 0;
     const int oy = m / p.GX, ox = m - oy * p.GX;
     b_ys0[it] = oy * p.ssy + p.y0;
     b_xs0[it] = ox * p.ssx + p.x0;
-    b_n[it] = blk * 128 + 4 * c4;
+    b_n[it] = blk * CW + 4 * c4;
     b_ok[it] = ok;
     b_krow[it] = krow;
-    b_lds[it] = (wcol * BK + krow) * 128 + 4 * c4;
+    b_lds[it] = (wcol * BK + krow) * CW + 4 * c4;
   }
 
   const int kbeg = split * p.chunks_per_split * BK;
@@ -263,15 +267,15 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
       const int idx = tid + it * NT;
-      if (idx < WC * BK * 32) st4(bs + b_lds[it], rb[it]);
+      if (idx < WC * BK * CW4) st4(bs + b_lds[it], rb[it]);
     }
   };
 
-  f32x16 acc[MT][4];
+  f32x16 acc[MT][NTC];
 #pragma unroll
   for (int t = 0; t < MT; ++t)
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < NTC; ++u)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
 
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
     const int buf = c & 1;
     if (c + 1 < nchunks) fetch(kbeg + (c + 1) * BK);
     const float* as = As + buf * A_STAGE;
-    const float* bs = Bs + buf * B_STAGE + wc * BK * 128 + 4 * li;
+    const float* bs = Bs + buf * B_STAGE + wc * BK * CW + NTC * li;
     if (!A_KCONTIG) {
       const float* ar = as + wr * MT * 32 + li;
 #pragma unroll
@@ -294,11 +298,11 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
         float a[MT];
 #pragma unroll
         for (int t = 0; t < MT; ++t) a[t] = ar[krow * ROWS + t * 32];
-        const f32x4 b4 = ld4(bs + krow * 128);
+        const fvec b4 = *reinterpret_cast<const fvec*>(bs + krow * CW);
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < NTC; ++u)
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b4[u], acc[t][u], 0, 0, 0);
       }
     } else {
@@ -310,11 +314,11 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
         for (int t = 0; t < MT; ++t) a4[t] = ld4(ar + t * 32 * APITCH + 8 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const f32x4 b4 = ld4(bs + (8 * q + 4 * lh + e) * 128);
+          const fvec b4 = *reinterpret_cast<const fvec*>(bs + (8 * q + 4 * lh + e) * CW);
 #pragma unroll
           for (int t = 0; t < MT; ++t)
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < NTC; ++u)
               acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t][e], b4[u], acc[t][u], 0, 0, 0);
         }
       }
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
   const int m = colid / p.nblk, blk = colid - m * p.nblk;
   const int oy = m / p.GX, ox = m - oy * p.GX;
   const int dpix = (oy * p.dsy + p.dy0) * p.DW + ox * p.dsx + p.dx0;
-  const int n = blk * 128 + 4 * li;
+  const int n = blk * CW + NTC * li;
   if (n >= N) return;
   float* base = (p.splits > 1 ? p.partial + (size_t)split * p.slab : p.dst) + (size_t)dpix * N + n;
   const bool fin = p.splits == 1;
@@ -339,29 +343,31 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
     for (int reg = 0; reg < 16; ++reg) {
       const int row = r0 + wr * MT * 32 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
       if (row >= p.R) continue;
-      f32x4 v = {acc[t][0][reg], acc[t][1][reg], acc[t][2][reg], acc[t][3][reg]};
+      fvec v;
+#pragma unroll
+      for (int u = 0; u < NTC; ++u) v[u] = acc[t][u][reg];
       float* dp = base + (size_t)row * p.DP * N;
       if (fin) {
         const float bv = p.bias ? p.bias[row] : 0.f;
         if (VEC) {
           if (p.scaleTargets != 0.f) {
-            const f32x4 o = ld4(dp);
+            const fvec o = *reinterpret_cast<const fvec*>(dp);
             v = p.scaleTargets * o + v;
           }
           v = v + bv;
           if (p.relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            for (int e = 0; e < NTC; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
           }
           if (p.mask) {
-            const f32x4 mk = ld4(p.mask + (dp - p.dst));
+            const fvec mk = *reinterpret_cast<const fvec*>(p.mask + (dp - p.dst));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] * p.post_scale : 0.f;
+            for (int e = 0; e < NTC; ++e) v[e] = mk[e] > 0.f ? v[e] * p.post_scale : 0.f;
           }
-          st4(dp, v);
+          *reinterpret_cast<fvec*>(dp) = v;
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < NTC; ++e) {
             if (n + e < N) {
               float x = v[e];
               if (p.scaleTargets != 0.f) x = p.scaleTargets * dp[e] + x;
@@ -374,10 +380,10 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
         }
       } else {
         if (VEC) {
-          st4(dp, v);
+          *reinterpret_cast<fvec*>(dp) = v;
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < NTC; ++e)
             if (n + e < N) dp[e] = v[e];
         }
       }
@@ -657,6 +663,18 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
   }
 }
 
+// first level of a two-level slab reduce (many splits, few elements: conv1's 512 x 14 112): group g sums
+// its `per` consecutive slabs into stage[g]; the plain reduce then finishes over the groups.
+__global__ void wg_reduce_group_kernel(float* __restrict__ stage, const float* __restrict__ partial, size_t total, int splits, int per) {
+  const int g = blockIdx.y;
+  const int k0 = g * per, k1 = min(splits, k0 + per);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = k0; k < k1; ++k) s += partial[(size_t)k * total + i];
+    stage[(size_t)g * total + i] = s;
+  }
+}
+
 __global__ void wg_reduce_kernel(float* __restrict__ dst, const float* __restrict__ partial, size_t total, int splits,
                                  float scaleTargets, float scaleOutput) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -689,11 +707,13 @@ void allow_big_lds(Kern kern, size_t lds) {
 
 // Launch one gather-GEMM.  `dst_elems` > 0 means the launch covers the whole destination matrix,
 // which makes a split-K (slab per split + deterministic reduce) legal.
-template <int WR, int WC, int MT, bool AK>
+template <int WR, int WC, int MT, int CW, bool AK>
 void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   constexpr int ROWS = WR * MT * 32;
   constexpr int A_STAGE = AK ? ROWS * (BK + 4) : BK * ROWS;
-  constexpr int B_STAGE = WC * BK * 128;
+  constexpr int B_STAGE = WC * BK * CW;
+  p.nblk = divup(p.N, CW);
+  p.ncols = p.G * p.nblk;
   const size_t lds = sizeof(float) * 2 * (A_STAGE + B_STAGE);
   p.row_tiles = divup(p.R, ROWS);
   p.col_tiles = divup(p.ncols, WC);
@@ -708,11 +728,11 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   int splits = 1;
   if (dst_elems > 0 && kchunks >= 16) {
     const double slots = kTargetBlocks;
-    const double flops = 2.0 * ROWS * (WC * 128.0) * (double)p.K;           // per tile, all K
+    const double flops = 2.0 * ROWS * (WC * (double)CW) * (double)p.K;           // per tile, all K
     double best_t = 1e30;
     for (int sp = 1; sp <= 16 && kchunks / sp >= 8; ++sp) {
       const double rounds = std::ceil(tiles * (double)sp / slots);
-      double t = rounds * (flops / sp) / (2 * 64.0 * 4 * 2.2e9 * 0.8);     // block time on half a CU at 80 %
+      double t = rounds * (flops / sp) / (64.0 * 4 * 2.2e9 * 0.8 / 2);     // block time on half a CU (64 FLOP/clk/SIMD) at 80 %
       if (sp > 1) t += sizeof(float) * (double)dst_elems * (2.0 * sp + 1) / 4.0e12 + 4e-6;
       if (t < best_t * 0.97) {
         best_t = t;
@@ -727,15 +747,15 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   p.partial = splits > 1 ? static_cast<float*>(workspace(sizeof(float) * dst_elems * splits)) : nullptr;
   dim3 grid(((tiles + 7) / 8) * 8, splits);
   dim3 block(WR * WC * 64);
-  static const std::string kname = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + (AK ? "kc" : "rc") + ">";
+  static const std::string kname = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + "," + (AK ? "kc" : "rc") + ">";
   {
     KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0);
     if (vec) {
-      allow_big_lds(gg_kernel<WR, WC, MT, AK, true>, lds);
-      hipLaunchKernelGGL((gg_kernel<WR, WC, MT, AK, true>), grid, block, lds, stream(), p);
+      allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, true>, lds);
+      hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, true>), grid, block, lds, stream(), p);
     } else {
-      allow_big_lds(gg_kernel<WR, WC, MT, AK, false>, lds);
-      hipLaunchKernelGGL((gg_kernel<WR, WC, MT, AK, false>), grid, block, lds, stream(), p);
+      allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, false>, lds);
+      hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, false>), grid, block, lds, stream(), p);
     }
   }
   if (splits > 1) {
@@ -752,12 +772,16 @@ void gg_run(GGParams& p, bool vec, size_t dst_elems) {
   // pick the row tile (128/64/32) that pads the fewest rows; ties go to the larger tile.  (The 96-row
   // 6-wave config measured 68 TFLOP/s vs 106 for the 128-row one, so 96-row problems — conv1 fprop,
   // conv2 dgrad — run 25 % padded on the 128-row kernel: 80 effective TFLOP/s.)
-  const int best = p.R > 64 ? 128 : (p.R > 32 ? 64 : 32);
-  switch (best) {
-    case 128: gg_launch_cfg<2, 2, 2, AK>(p, vec, dst_elems); break;   // 128 rows x 2 wave-columns
-    case 64: gg_launch_cfg<2, 2, 1, AK>(p, vec, dst_elems); break;    //  64 rows x 2
-    default: gg_launch_cfg<1, 4, 1, AK>(p, vec, dst_elems); break;    //  32 rows x 4
-  }
+  // row tile by problem height: 128 rows (2x2 waves of 64x128), 96 rows (4 waves of 96x64: conv1 fprop,
+  // conv2 dgrad), 64 and 32 rows for small layers.
+  if (p.R > 96 || (p.R > 64 && p.R <= 96 && (!vec)))
+    gg_launch_cfg<2, 2, 2, 128, AK>(p, vec, dst_elems);
+  else if (p.R > 64)
+    gg_launch_cfg<1, 4, 3, 64, AK>(p, vec, dst_elems);
+  else if (p.R > 32)
+    gg_launch_cfg<2, 2, 1, 128, AK>(p, vec, dst_elems);
+  else
+    gg_launch_cfg<1, 4, 1, 128, AK>(p, vec, dst_elems);
 }
 
 template <int WM, int WN, int MT, int NTL>
@@ -784,7 +808,8 @@ void wg_launch_cfg(WGParams& p, bool vec) {
   p.chunks_per_split = divup(p.chunks_total, splits);
   splits = divup(p.chunks_total, p.chunks_per_split);
   p.splits = splits;
-  p.partial = splits > 1 ? static_cast<float*>(workspace(sizeof(float) * total * splits)) : nullptr;
+  const int groups = splits > 64 ? 32 : 1;   // two-level reduce when the slab count dwarfs the tile
+  p.partial = splits > 1 ? static_cast<float*>(workspace(sizeof(float) * total * (splits + (groups > 1 ? groups : 0)))) : nullptr;
   dim3 grid(((tiles * splits + 7) / 8) * 8), block(WM * WN * 64);
   static const std::string kname = "wg_kernel<" + std::to_string(WM) + "," + std::to_string(WN) + "," + std::to_string(MT) + "," + std::to_string(NTL) + ">";
   {
@@ -801,7 +826,16 @@ void wg_launch_cfg(WGParams& p, bool vec) {
     KernelTimer timer("wg_reduce_kernel", t_op, 0.0, sizeof(float) * (double)total * (splits + 1));
     size_t nb = (total + 255) / 256;
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream(), p.dst, p.partial, total, splits, p.scaleTargets,
+    const float* slabs = p.partial;
+    int nslabs = splits;
+    if (groups > 1) {
+      float* stage = p.partial + (size_t)splits * total;
+      const int per = divup(splits, groups);
+      hipLaunchKernelGGL(wg_reduce_group_kernel, dim3((unsigned)nb, divup(splits, per)), dim3(256), 0, stream(), stage, p.partial, total, splits, per);
+      slabs = stage;
+      nslabs = divup(splits, per);
+    }
+    hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream(), p.dst, slabs, total, nslabs, p.scaleTargets,
                        p.scaleOutput);
   }
 }

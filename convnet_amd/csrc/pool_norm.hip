@@ -257,6 +257,111 @@ __global__ void rnorm_undo2_kernel(const float* __restrict__ in, const float* __
   }
 }
 
+// ---- LDS-tiled response norm: read-once / write-once ------------------------------------------------
+// A block stages ALL channels of LT consecutive locations in LDS (C x LT floats; every row is a
+// contiguous 4*LT-byte run of the tensor), lanes = (location, channel group) slide their windows over
+// LDS, so HBM sees exactly the algorithmic bytes: 8 B/element forward, 12 B/element backward (the global-
+// memory walkers above re-read each element ~3x through L2 and, backward, round-trip two temporaries).
+template <int LT>
+__device__ __forceinline__ void rn_stage(const float* __restrict__ g, float* __restrict__ s, size_t locs, size_t l0, int C, bool vec) {
+  constexpr int L4 = LT / 4;
+  for (int idx = threadIdx.x; idx < C * L4; idx += blockDim.x) {
+    const int c = idx / L4, q = idx - c * L4;
+    const size_t l = l0 + 4 * q;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (l < locs) v = ldv(g + (size_t)c * locs + l, 0, (int)min((size_t)4, locs - l), vec);
+    *reinterpret_cast<f32x4*>(s + c * LT + 4 * q) = v;
+  }
+}
+
+template <int LT>
+__global__ void rnorm_fwd_lds_kernel(const float* __restrict__ in, float* __restrict__ out, size_t locs, int C, int sizeF, float addScale,
+                                     float powScale, bool blocked, bool vec) {
+  extern __shared__ __attribute__((aligned(16))) float rn_smem[];
+  float* xs = rn_smem;   // [C][LT]
+  const size_t l0 = (size_t)blockIdx.x * LT;
+  rn_stage<LT>(in, xs, locs, l0, C, vec);
+  __syncthreads();
+  const int l = threadIdx.x % LT, g = threadIdx.x / LT, G = blockDim.x / LT;
+  const int cg = (C + G - 1) / G, j0 = g * cg, j1 = min(C, j0 + cg);
+  if (l0 + l >= locs || j0 >= j1) return;
+  int ps, pe;
+  {
+    int e0;
+    win_fwd(j0, C, sizeF, blocked, ps, e0);
+    pe = ps;
+  }
+  float sum = 0.f;
+  for (int j = j0; j < j1; ++j) {
+    int s, e;
+    win_fwd(j, C, sizeF, blocked, s, e);
+    for (int i = ps; i < s; ++i) { const float v = xs[i * LT + l]; sum -= v * v; }
+    for (int i = pe; i < e; ++i) { const float v = xs[i * LT + l]; sum += v * v; }
+    // u^(-b) = exp2(-b * log2(u)), u >= 1: two quarter-rate transcendentals instead of ~100 VALU of powf
+    // (the reference's own GPU path uses __powf, cudamat_conv_gemm.cu:458); relative error ~1e-6.
+    out[(size_t)j * locs + l0 + l] = xs[j * LT + l] * exp2f(-powScale * __log2f(1.f + addScale * sum));
+    ps = s;
+    pe = e;
+  }
+}
+
+template <int LT>
+__global__ void rnorm_undo_lds_kernel(const float* __restrict__ dout, const float* __restrict__ in, float* __restrict__ out, size_t locs, int C,
+                                      int sizeF, float addScale, float powScale, bool blocked, bool vec) {
+  extern __shared__ __attribute__((aligned(16))) float rn_smem[];
+  float* xs = rn_smem;            // [C][LT] inputs
+  float* ds = xs + C * LT;        // [C][LT] out-grads, then "scaled" = dout * den^(b/(b+1))
+  float* ps_ = ds + C * LT;       // [C][LT] prod   = dout * in * den,  den = (1 + a*S)^(-b-1)
+  const size_t l0 = (size_t)blockIdx.x * LT;
+  rn_stage<LT>(in, xs, locs, l0, C, vec);
+  rn_stage<LT>(dout, ds, locs, l0, C, vec);
+  __syncthreads();
+  const int l = threadIdx.x % LT, g = threadIdx.x / LT, G = blockDim.x / LT;
+  const int cg = (C + G - 1) / G, j0 = g * cg, j1 = min(C, j0 + cg);
+  const bool live = l0 + l < locs && j0 < j1;
+  if (live) {
+    int ps, pe;
+    {
+      int e0;
+      win_fwd(j0, C, sizeF, blocked, ps, e0);
+      pe = ps;
+    }
+    float sum = 0.f;
+    for (int j = j0; j < j1; ++j) {
+      int s, e;
+      win_fwd(j, C, sizeF, blocked, s, e);
+      for (int i = ps; i < s; ++i) { const float v = xs[i * LT + l]; sum -= v * v; }
+      for (int i = pe; i < e; ++i) { const float v = xs[i * LT + l]; sum += v * v; }
+      const float lg = __log2f(1.f + addScale * sum);
+      const float den = exp2f((-powScale - 1.f) * lg);          // (1 + a*S)^(-b-1)
+      const float d = ds[j * LT + l];
+      ps_[j * LT + l] = d * xs[j * LT + l] * den;
+      ds[j * LT + l] = d * exp2f(-powScale * lg);               // d * den^(b/(b+1)) = d * (1 + a*S)^(-b)
+      ps = s;
+      pe = e;
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const float k2 = 2 * addScale * powScale;
+  int ps, pe;
+  {
+    int e0;
+    win_bwd(j0, C, sizeF, blocked, ps, e0);
+    pe = ps;
+  }
+  float sum = 0.f;
+  for (int j = j0; j < j1; ++j) {
+    int s, e;
+    win_bwd(j, C, sizeF, blocked, s, e);
+    for (int i = ps; i < s; ++i) sum -= ps_[i * LT + l];
+    for (int i = pe; i < e; ++i) sum += ps_[i * LT + l];
+    out[(size_t)j * locs + l0 + l] = ds[j * LT + l] - k2 * xs[j * LT + l] * sum;
+    ps = s;
+    pe = e;
+  }
+}
+
 namespace {
 
 inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -361,6 +466,18 @@ void ResponseNormCrossMapGemm(cudamat* images, cudamat* targets, int numFilters,
   const size_t locs = total / numFilters;
   const bool vec = locs % 4 == 0 && a16(images->data_device) && a16(targets->data_device);
   KernelTimer timer("rnorm_fwd_kernel", "rnorm_fwd", 0.0, 8.0 * total);
+  {
+    const int C = numFilters;
+    const int LT = C <= 192 ? 64 : (C <= 384 ? 32 : (C <= 768 ? 16 : 0));
+    if (LT) {   // LDS-tiled, read-once/write-once
+      const size_t smem = sizeof(float) * (size_t)C * LT;
+      const dim3 grid((unsigned)((locs + LT - 1) / LT)), block(256);
+      if (LT == 64) hipLaunchKernelGGL(rnorm_fwd_lds_kernel<64>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec);
+      else if (LT == 32) hipLaunchKernelGGL(rnorm_fwd_lds_kernel<32>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec);
+      else hipLaunchKernelGGL(rnorm_fwd_lds_kernel<16>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec);
+      return;
+    }
+  }
   int cseg, nseg;
   rnorm_segments((locs + 3) / 4, numFilters, sizeF, cseg, nseg);
   hipLaunchKernelGGL(rnorm_fwd_kernel, dim3(grid_for((locs + 3) / 4 * nseg)), dim3(256), 0, stream(), images->data_device, targets->data_device, locs,
@@ -375,6 +492,20 @@ void ResponseNormCrossMapUndoGemm(cudamat* outGrads, cudamat* inputs, cudamat* t
   const size_t total = numel(inputs);
   CHIP_REQUIRE(numel(targets) == total && numel(outGrads) == total && numFilters > 0 && total % numFilters == 0 && sizeF > 0);
   const size_t locs = total / numFilters;
+  {
+    const int C = numFilters;
+    const int LT = C <= 64 ? 64 : (C <= 128 ? 32 : (C <= 256 ? 16 : 0));
+    if (LT) {
+      const bool vec = locs % 4 == 0 && a16(outGrads->data_device) && a16(inputs->data_device) && a16(targets->data_device);
+      KernelTimer timer("rnorm_undo_kernels", "rnorm_undo", 0.0, 12.0 * total);
+      const size_t smem = sizeof(float) * 3 * (size_t)C * LT;
+      const dim3 grid((unsigned)((locs + LT - 1) / LT)), block(256);
+      if (LT == 64) hipLaunchKernelGGL(rnorm_undo_lds_kernel<64>, grid, block, smem, stream(), outGrads->data_device, inputs->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec);
+      else if (LT == 32) hipLaunchKernelGGL(rnorm_undo_lds_kernel<32>, grid, block, smem, stream(), outGrads->data_device, inputs->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec);
+      else hipLaunchKernelGGL(rnorm_undo_lds_kernel<16>, grid, block, smem, stream(), outGrads->data_device, inputs->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec);
+      return;
+    }
+  }
   const size_t padded = (total + 63) / 64 * 64;
   float* prod = static_cast<float*>(workspace(sizeof(float) * padded * 2));
   float* scaled = prod + padded;

