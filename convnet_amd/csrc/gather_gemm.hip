@@ -167,11 +167,27 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
       }
     }
   }
-  auto fetch_vec = [&]() {
+  // Direct-to-LDS staging (global_load_lds_dwordx4): both tiles are stored lane-linear (LDS float offset
+  // = 4 * slot index), so one wave-instruction fills 1 KiB = two 512-byte rows with no VGPR round trip, no
+  // ds_write pass and nothing to wait for before the stage's closing barrier (whose fence drains vmcnt).
+  // Ablation on conv4: the register-staged ds_write pass cost 7 % of the kernel.  Out-of-range lanes read
+  // the zero page; lanes past the tile are masked off.  (The k-contiguous A tile is padded, not
+  // lane-linear, so it keeps the register path.)
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  constexpr bool GLDS_A = VEC && !A_KCONTIG, GLDS_B = VEC;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto fetch_vec = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const bool ok = a_ok[it] && a_k[it] < kend;
-      ra[it] = ld4(ok ? a_ptr[it] : p.zero);
+      const float* src = ok ? a_ptr[it] : p.zero;
+      if (GLDS_A) {
+        if (tid + it * NT < BK * (ROWS / 4))
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(As + buf * A_STAGE + 4 * (64 * wave_u + it * NT)), 16, 0, 0);
+      } else {
+        ra[it] = ld4(src);
+      }
       a_k[it] += BK;
       a_ptr[it] += A_KCONTIG ? (size_t)BK : (size_t)p.lda * BK;
     }
@@ -180,7 +196,13 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
       const int ys = b_ys0[it] + p.dir * s_a[it], xs = b_xs0[it] + p.dir * s_b[it];
       const bool ok = b_ok[it] && s_k[it] < kend && (unsigned)ys < (unsigned)p.SH && (unsigned)xs < (unsigned)p.SW;
       const unsigned off = (unsigned)((s_ch[it] * p.SH + ys) * p.SW + xs) * (unsigned)N + (unsigned)b_n[it];
-      rb[it] = ld4(ok ? p.src + off : p.zero);
+      const float* src = ok ? p.src + off : p.zero;
+      if (GLDS_B) {
+        if (tid + it * NT < WC * BK * CW4)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(Bs + buf * B_STAGE + 4 * (64 * wave_u + it * NT)), 16, 0, 0);
+      } else {
+        rb[it] = ld4(src);
+      }
       s_k[it] += BK;
       int b = s_b[it] + db, a = s_a[it] + da, ch = s_ch[it] + dch;
       if (b >= p.TX) { b -= p.TX; a += 1; }
@@ -189,9 +211,9 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
     }
   };
 
-  auto fetch = [&](int k0) {
+  auto fetch = [&](int k0, int buf) {
     if (VEC) {
-      fetch_vec();   // stateful: called with k0 = kbeg, kbeg+BK, ... in order
+      fetch_vec(buf);   // stateful: called with k0 = kbeg, kbeg+BK, ... in order
       return;
     }
 #pragma unroll
@@ -254,20 +276,24 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
   auto stash = [&](int buf) {
     float* as = As + buf * A_STAGE;
     float* bs = Bs + buf * B_STAGE;
+    if (!GLDS_A) {
 #pragma unroll
-    for (int it = 0; it < NA; ++it) {
-      const int idx = tid + it * NT;
-      if (!A_KCONTIG) {
-        if (idx < BK * (ROWS / 4)) st4(as + 4 * idx, ra[it]);
-      } else {
-        const int row = idx / (BK / 4), c4 = idx % (BK / 4);
-        if (idx < ROWS * (BK / 4)) st4(as + row * APITCH + 4 * c4, ra[it]);
+      for (int it = 0; it < NA; ++it) {
+        const int idx = tid + it * NT;
+        if (!A_KCONTIG) {
+          if (idx < BK * (ROWS / 4)) st4(as + 4 * idx, ra[it]);
+        } else {
+          const int row = idx / (BK / 4), c4 = idx % (BK / 4);
+          if (idx < ROWS * (BK / 4)) st4(as + row * APITCH + 4 * c4, ra[it]);
+        }
       }
     }
+    if (!GLDS_B) {
 #pragma unroll
-    for (int it = 0; it < NB; ++it) {
-      const int idx = tid + it * NT;
-      if (idx < WC * BK * CW4) st4(bs + b_lds[it], rb[it]);
+      for (int it = 0; it < NB; ++it) {
+        const int idx = tid + it * NT;
+        if (idx < WC * BK * CW4) st4(bs + b_lds[it], rb[it]);
+      }
     }
   };
 
@@ -280,14 +306,14 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
       for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
 
   if (nchunks > 0) {
-    fetch(kbeg);
+    fetch(kbeg, 0);
     stash(0);
   }
   __syncthreads();
 
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
-    if (c + 1 < nchunks) fetch(kbeg + (c + 1) * BK);
+    if (c + 1 < nchunks) fetch(kbeg + (c + 1) * BK, buf ^ 1);
     const float* as = As + buf * A_STAGE;
     const float* bs = Bs + buf * B_STAGE + wc * BK * CW + NTC * li;
     if (!A_KCONTIG) {
