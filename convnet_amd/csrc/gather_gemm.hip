@@ -318,18 +318,27 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
     const float* bs = Bs + buf * B_STAGE + wc * BK * CW + NTC * li;
     if (!A_KCONTIG) {
       const float* ar = as + wr * MT * 32 + li;
+      // fragments for step kk+1 are requested before the MFMAs of step kk
+      float a[2][MT];
+      fvec b4[2];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) a[0][t] = ar[lh * ROWS + t * 32];
+      b4[0] = *reinterpret_cast<const fvec*>(bs + lh * CW);
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
-        const int krow = 2 * kk + lh;
-        float a[MT];
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < BK / 2) {
+          const int krow = 2 * (kk + 1) + lh;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) a[t] = ar[krow * ROWS + t * 32];
-        const fvec b4 = *reinterpret_cast<const fvec*>(bs + krow * CW);
+          for (int t = 0; t < MT; ++t) a[nxt][t] = ar[krow * ROWS + t * 32];
+          b4[nxt] = *reinterpret_cast<const fvec*>(bs + krow * CW);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
           for (int u = 0; u < NTC; ++u)
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b4[u], acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], b4[cur][u], acc[t][u], 0, 0, 0);
       }
     } else {
       const float* ar = as + (wr * MT * 32 + li) * APITCH + 4 * lh;

@@ -124,6 +124,106 @@ __global__ void pool_undo_kernel(const float* __restrict__ images, const float* 
   }
 }
 
+// Fixed-window variants (square K x K, stride S known at compile time; N % 4 == 0): grid = (W*nvec/256, rows,
+// C) so no 64-bit index division, and every window load is issued up front from a clamped address
+// (select, not branch) so a lane has K*K (fwd) or 2*ceil(K/S)^2 (undo) independent 16-byte loads in flight.
+// Same visiting order as the generic kernels, so the fp32 sums are bit-identical to them.
+template <bool MAX, int K, int S>
+__global__ void __launch_bounds__(256) pool_fwd_fixed_kernel(const float* __restrict__ in, float* __restrict__ out, PoolGeo g, float st,
+                                                             float so) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= g.Mx * g.nvec) return;
+  const int ox = j / g.nvec, n = 4 * (j - ox * g.nvec);
+  const int oy = blockIdx.y, c = blockIdx.z;
+  const int ys = oy * S + g.py, xs = ox * S + g.px;
+  const float* plane = in + (size_t)c * g.H * g.W * g.N + n;
+  f32x4 v[K][K];
+  bool ok[K][K];
+#pragma unroll
+  for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < K; ++dx) {
+      const int y = ys + dy, x = xs + dx;
+      ok[dy][dx] = y >= 0 && y < g.H && x >= 0 && x < g.W;
+      const size_t o = ok[dy][dx] ? ((size_t)y * g.W + x) * g.N : 0;
+      v[dy][dx] = *reinterpret_cast<const f32x4*>(plane + o);
+    }
+  f32x4 acc = MAX ? f32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX} : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < K; ++dx)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (MAX) acc[e] = (ok[dy][dx] && acc[e] < v[dy][dx][e]) ? v[dy][dx][e] : acc[e];
+        else acc[e] = ok[dy][dx] ? acc[e] + v[dy][dx][e] : acc[e];
+      }
+  if (!MAX) {
+    const int y0 = max(0, ys), y1 = min(g.H, ys + K), x0 = max(0, xs), x1 = min(g.W, xs + K);
+    const float cnt = (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = acc[e] / cnt;
+  }
+  float* op = out + ((size_t)(c * g.My + oy) * g.Mx + ox) * g.N + n;
+  f32x4 res = so * acc;
+  if (st != 0.f) res = st * *reinterpret_cast<const f32x4*>(op) + res;
+  *reinterpret_cast<f32x4*>(op) = res;
+}
+
+template <bool MAX, int K, int S>
+__global__ void __launch_bounds__(256) pool_undo_fixed_kernel(const float* __restrict__ images, const float* __restrict__ grads,
+                                                              const float* __restrict__ acts, float* __restrict__ out, PoolGeo g, float st,
+                                                              bool relu_mask) {
+  constexpr int CV = (K + S - 1) / S;   // pooled coordinates that can cover one input coordinate
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= g.W * g.nvec) return;
+  const int ix = j / g.nvec, n = 4 * (j - ix * g.nvec);
+  const int iy = blockIdx.y, c = blockIdx.z;
+  const size_t t = ((size_t)(c * g.H + iy) * g.W + ix) * g.N + n;
+  f32x4 img = {0.f, 0.f, 0.f, 0.f};
+  if (MAX) img = *reinterpret_cast<const f32x4*>(images + t);
+  const int ty = iy - g.py, tx = ix - g.px;
+  const int oyh = ty >= 0 ? ty / S : -1, oxh = tx >= 0 ? tx / S : -1;
+  const size_t pplane = (size_t)c * g.My * g.Mx * g.N + n;
+  f32x4 gv[CV][CV], av[CV][CV];
+  float wt[CV][CV];
+  bool ok[CV][CV];
+#pragma unroll
+  for (int a = 0; a < CV; ++a) {
+    const int oy = oyh - (CV - 1 - a);
+    const bool vy = oy >= 0 && oy < g.My && oy * S + K > ty;
+    const float ry = fminf((float)g.H, (float)(g.py + oy * S + K)) - fmaxf(0.f, (float)(g.py + oy * S));
+#pragma unroll
+    for (int b = 0; b < CV; ++b) {
+      const int ox = oxh - (CV - 1 - b);
+      ok[a][b] = vy && ox >= 0 && ox < g.Mx && ox * S + K > tx;
+      const size_t o = pplane + (ok[a][b] ? ((size_t)oy * g.Mx + ox) * g.N : 0);
+      gv[a][b] = *reinterpret_cast<const f32x4*>(grads + o);
+      if (MAX) av[a][b] = *reinterpret_cast<const f32x4*>(acts + o);
+      else {
+        const float rx = fminf((float)g.W, (float)(g.px + ox * S + K)) - fmaxf(0.f, (float)(g.px + ox * S));
+        wt[a][b] = 1.0f / (rx * ry);
+      }
+    }
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < CV; ++a)
+#pragma unroll
+    for (int b = 0; b < CV; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (MAX) acc[e] += (ok[a][b] && img[e] == av[a][b][e]) ? gv[a][b][e] : 0.f;
+        else acc[e] = ok[a][b] ? acc[e] + gv[a][b][e] * wt[a][b] : acc[e];
+      }
+  if (st != 0.f) acc = st * *reinterpret_cast<const f32x4*>(out + t) + acc;
+  if (MAX && relu_mask) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = img[e] > 0.f ? acc[e] : 0.f;
+  }
+  *reinterpret_cast<f32x4*>(out + t) = acc;
+}
+
 // ---- cross-map response norm --------------------------------------------------------------------------
 // One lane owns 4 consecutive "locations" (a location = one (pixel, image); locations are
 // contiguous in memory) and walks the channel axis with the reference's sliding-window update
@@ -401,6 +501,14 @@ PoolGeo pool_geo(const Shape4D* in, const Shape4D* out, const ConvDesc& d, const
   return g;
 }
 
+// 10*K+S when a compile-time (K, S) instantiation exists and its 3-D grid is legal, else 0 (generic kernel)
+inline int fixed_window(const PoolGeo& g, bool vec) {
+  if (!vec || g.Ky != g.Kx || g.sy != g.sx || g.H > 65535 || g.C > 65535) return 0;
+  if (g.Ky == 3 && g.sy == 2) return 32;
+  if (g.Ky == 2 && g.sy == 2) return 22;
+  return 0;
+}
+
 template <bool MAX>
 void pool_fwd(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, const ConvDesc& d, float st, float so) {
   const PoolGeo g = pool_geo(is, ts, d, images, targets);
@@ -408,8 +516,15 @@ void pool_fwd(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, const
   const size_t total = (size_t)g.C * g.My * g.Mx * g.nvec;
   // algorithmic bytes: read input once, write output once
   KernelTimer timer(MAX ? "pool_fwd_kernel<max>" : "pool_fwd_kernel<avg>", "pool_fwd", 0.0, 4.0 * g.N * g.C * ((double)g.H * g.W + (double)g.My * g.Mx));
-  hipLaunchKernelGGL(pool_fwd_kernel<MAX>, dim3(grid_for(total)), dim3(256), 0, stream(), images->data_device, targets->data_device, g, st,
-                     so, vec);
+  const int fx = fixed_window(g, vec);
+  const dim3 fgrid(divup(g.Mx * g.nvec, 256), g.My, g.C);
+  if (fx == 32)
+    hipLaunchKernelGGL((pool_fwd_fixed_kernel<MAX, 3, 2>), fgrid, dim3(256), 0, stream(), images->data_device, targets->data_device, g, st, so);
+  else if (fx == 22)
+    hipLaunchKernelGGL((pool_fwd_fixed_kernel<MAX, 2, 2>), fgrid, dim3(256), 0, stream(), images->data_device, targets->data_device, g, st, so);
+  else
+    hipLaunchKernelGGL(pool_fwd_kernel<MAX>, dim3(grid_for(total)), dim3(256), 0, stream(), images->data_device, targets->data_device, g,
+                       st, so, vec);
 }
 
 template <bool MAX>
@@ -421,8 +536,19 @@ void pool_undo(cudamat* images, cudamat* grads, cudamat* acts, cudamat* targets,
   const size_t total = (size_t)g.C * g.H * g.W * g.nvec;
   KernelTimer timer(MAX ? "pool_undo_kernel<max>" : "pool_undo_kernel<avg>", "pool_undo", 0.0,
                     4.0 * g.N * g.C * ((MAX ? 2.0 : 1.0) * g.H * g.W + (MAX ? 2.0 : 1.0) * g.My * g.Mx + (st != 0.f ? (double)g.H * g.W : 0.0)));
-  hipLaunchKernelGGL(pool_undo_kernel<MAX>, dim3(grid_for(total)), dim3(256), 0, stream(), MAX ? images->data_device : nullptr,
-                     grads->data_device, MAX ? acts->data_device : nullptr, targets->data_device, g, st, vec, relu_mask);
+  const float* im = MAX ? images->data_device : nullptr;
+  const float* ac = MAX ? acts->data_device : nullptr;
+  const int fx = fixed_window(g, vec);
+  const dim3 fgrid(divup(g.W * g.nvec, 256), g.H, g.C);
+  if (fx == 32)
+    hipLaunchKernelGGL((pool_undo_fixed_kernel<MAX, 3, 2>), fgrid, dim3(256), 0, stream(), im, grads->data_device, ac, targets->data_device, g,
+                       st, relu_mask);
+  else if (fx == 22)
+    hipLaunchKernelGGL((pool_undo_fixed_kernel<MAX, 2, 2>), fgrid, dim3(256), 0, stream(), im, grads->data_device, ac, targets->data_device, g,
+                       st, relu_mask);
+  else
+    hipLaunchKernelGGL(pool_undo_kernel<MAX>, dim3(grid_for(total)), dim3(256), 0, stream(), im, grads->data_device, ac,
+                       targets->data_device, g, st, vec, relu_mask);
 }
 
 }  // namespace
