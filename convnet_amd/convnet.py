@@ -18,6 +18,8 @@ What changed relative to the reference, and why (MI355X-first):
 import sys
 from collections import deque
 
+import torch
+
 from . import pbtxt
 from .edge import ConvEdge, Edge, EdgeWithWeight, FCEdge
 from .layer import Layer, SoftmaxLayer
@@ -25,10 +27,19 @@ from .matrix import Matrix
 
 
 class ConvNet:
-    def __init__(self, model, fused=False, process_id=0, num_processes=1, verbose=False, exchange=None):
-        """``model``: path to a pbtxt file, pbtxt text, or a parsed pbtxt.Model."""
+    def __init__(self, model, fused=False, process_id=0, num_processes=1, verbose=False, exchange=None, overlap_update=None):
+        """``model``: path to a pbtxt file, pbtxt text, or a parsed pbtxt.Model.
+        ``overlap_update`` (default off): inside TrainOneBatch each edge's optimizer step is enqueued on a second
+        HIP stream as soon as that edge's wgrad + dgrad (and, data-parallel, its gradient bucket's all-reduce)
+        are done.  Same arithmetic as the reference's serial UpdateWeights (bit-identical, tested).  Measured on
+        one MI355X it is throughput-neutral (18.34 vs 18.36 ms/step): the co-running HBM-bound update kernels take
+        CU slots from the MFMA kernels and slow them by what they save, so it stays opt-in."""
         self.verbose = verbose
         self.fused = fused
+        self.overlap_update_ = bool(overlap_update)
+        self.side_stream_ = None
+        self._pending_updates = []     # [(edge, event on the main stream after its dgrad, held back?)]
+        self._in_train_step = False
         self.process_id_ = process_id
         self.num_processes_ = num_processes
         self.is_root_ = process_id == 0
@@ -228,6 +239,13 @@ class ConvNet:
         # ConvNet::Bprop(output, input, edge), src/convnet.cc:362-375
         if edge.IsBackPropBlocked():
             return
+        side = self._in_train_step and self.side_stream_ is not None
+        if side and isinstance(edge, ConvEdge) and any(held for _, _, held in self._pending_updates):
+            # the FC updates held back so far start now, beside this conv edge's MFMA-bound backward
+            now = torch.cuda.Event()
+            now.record(torch.cuda.current_stream())
+            self._pending_updates = [(e, now, False) for e, _, _ in self._pending_updates]
+            self._flush_updates(final=False)
         edge.ComputeOuter(input.GetState(), output.GetDeriv())
         if self.exchange_ is not None and edge in self.edge_slices_:
             self.exchange_.GradReady(edge)      # wgrad of this edge is final: start its all-reduce
@@ -237,6 +255,37 @@ class ConvNet:
                 edge.ComputeDown(output.GetDeriv(), input.GetState(), output.GetState(), input.GetDeriv(), overwrite, fuse_mask=fuse_mask)
             else:
                 edge.ComputeDown(output.GetDeriv(), input.GetState(), output.GetState(), input.GetDeriv(), overwrite)
+        if side and isinstance(edge, EdgeWithWeight):
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())   # wgrad AND dgrad (which reads the weights) are enqueued
+            # An FC edge's backward at batch <= a few hundred is itself HBM-bound (it streams the weight matrix
+            # three times), so running its update beside it gains nothing: hold it until a conv edge's backward
+            # (MFMA-bound) begins.  Conv updates are small and start at once.
+            self._pending_updates.append((edge, ev, isinstance(edge, FCEdge)))
+            self._flush_updates(final=False)
+
+    def _flush_updates(self, final):
+        """Enqueue on the side stream the optimizer step of every pending edge whose gradient is final."""
+        keep = []
+        for edge, ev, held in self._pending_updates:
+            if held and not final:
+                keep.append((edge, ev, held))
+                continue
+            bucket_ev = None
+            if self.exchange_ is not None and edge in self.edge_slices_:
+                state = self.exchange_.BucketState(edge)
+                if state == "pending":
+                    if final:
+                        raise RuntimeError(f"gradient bucket of {edge.GetName()} was never exchanged")
+                    keep.append((edge, ev, held))
+                    continue
+                bucket_ev = state
+            self.side_stream_.wait_event(ev)
+            if bucket_ev is not None:
+                self.side_stream_.wait_event(bucket_ev)
+            with Matrix.OnStream(self.side_stream_):
+                edge.UpdateWeights()
+        self._pending_updates = keep
 
     def _fused_down_scale(self, l):
         """If layer l's dropout' + ReLU' can ride in its only outgoing edge's ComputeDown epilogue, return the
@@ -289,6 +338,14 @@ class ConvNet:
 
     # ---- update: src/convnet.cc:440-450 -------------------------------------------------------------------
     def UpdateWeights(self):
+        if self._in_train_step and self.side_stream_ is not None:
+            # every edge went through _bprop_edge: drain what is still waiting for its bucket, then make the
+            # main stream (next Fprop reads the weights) wait for the side stream
+            self._flush_updates(final=True)
+            done = torch.cuda.Event()
+            done.record(self.side_stream_)
+            torch.cuda.current_stream().wait_event(done)
+            return
         for e in self.edges_:
             if e.IsBackPropBlocked():
                 continue
@@ -314,11 +371,17 @@ class ConvNet:
             l.NotifyStart()
         if self.exchange_ is not None:
             self.exchange_.StartStep()
+        if self.overlap_update_ and self.side_stream_ is None and torch.cuda.is_available():
+            self.side_stream_ = torch.cuda.Stream()
         self.GetBatch(self.train_dataset_)
         self.Fprop(True)
         self.ComputeDeriv()
         error = self.GetLoss()
-        self.Bprop()
-        self.UpdateWeights()
+        self._in_train_step = True
+        try:
+            self.Bprop()
+            self.UpdateWeights()
+        finally:
+            self._in_train_step = False
         self.current_iter_ += 1
         return error

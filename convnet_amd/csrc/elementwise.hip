@@ -267,11 +267,16 @@ __global__ void rows_sq_kernel(float* __restrict__ g, float* __restrict__ w, flo
 }
 
 __global__ void row_factor_kernel(const float* __restrict__ partial, int nchunks, int rows, float norm, int constraint, float* __restrict__ factor) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
+  // block = 64 rows x 4 chunk lanes; lane q sums chunks q, q+4, ... then the 4 partials combine in fixed order
+  __shared__ float sh[4][64];
+  const int r = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
   float s = 0.f;
-  for (int k = 0; k < nchunks; ++k) s += partial[(size_t)k * rows + r];
-  s = sqrtf(s);
+  if (r < rows)
+    for (int k = q; k < nchunks; k += 4) s += partial[(size_t)k * rows + r];
+  sh[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q != 0 || r >= rows) return;
+  s = sqrtf((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]));
   factor[r] = (constraint == 1 || s > norm) ? norm / s : 1.f;
 }
 
@@ -301,7 +306,7 @@ inline int rows_normlimit(float* g, float* w_in, float* w_out, float* h, int row
     hipLaunchKernelGGL(rows_sq_kernel<true>, grid, dim3(256), 0, stream(), g, w_in, h, rows, cols, chunk, partial, l2, clip, eps, mom);
   else
     hipLaunchKernelGGL(rows_sq_kernel<false>, grid, dim3(256), 0, stream(), nullptr, w_in, nullptr, rows, cols, chunk, partial, 0.f, 0.f, 0.f, 0.f);
-  hipLaunchKernelGGL(row_factor_kernel, dim3(divup(rows, 256)), dim3(256), 0, stream(), partial, nchunks, rows, norm, constraint, factor);
+  hipLaunchKernelGGL(row_factor_kernel, dim3(divup(rows, 64)), dim3(256), 0, stream(), partial, nchunks, rows, norm, constraint, factor);
   hipLaunchKernelGGL(row_scale_kernel, grid, dim3(256), 0, stream(), w_in, w_out, rows, cols, chunk, factor);
   return launch_status();
 }

@@ -10,38 +10,39 @@
 namespace chip {
 namespace {
 hipStream_t g_stream = nullptr;
-void* g_ws = nullptr;
-size_t g_ws_bytes = 0;
 std::string g_last_error;
 ConvnetHipKernelInfo g_info = {"none", 0.0, 0, 1};
 }  // namespace
 
 hipStream_t stream() { return g_stream; }
 
-void* workspace(size_t bytes) {
-  if (bytes <= g_ws_bytes) return g_ws;
-  // Grow: wait for in-flight users of the old arena, then replace it.  Rounded up generously so
-  // a training run reaches steady state after the first step.
+// Scratch arenas are per stream: a host that drives a second stream through convnet_hip_set_stream (e.g.
+// optimizer updates beside the backward pass) gets its own split-K slabs, so concurrent launches on two
+// streams never share a base pointer.  Grow-only; growth waits for that stream's in-flight users first and
+// rounds up generously so a training run reaches steady state after the first step.
+namespace {
+struct Arena {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+std::map<hipStream_t, Arena> g_arena[2];
+
+void* arena_get(int which, size_t bytes, size_t slack) {
+  Arena& a = g_arena[which][g_stream];
+  if (bytes <= a.cap) return a.p;
   CHIP_CHECK(hipStreamSynchronize(g_stream));
-  if (g_ws) CHIP_CHECK(hipFree(g_ws));
-  size_t want = ((bytes + (size_t(1) << 22)) >> 20) << 20;
-  CHIP_CHECK(hipMalloc(&g_ws, want));
-  g_ws_bytes = want;
-  return g_ws;
+  if (a.p) CHIP_CHECK(hipFree(a.p));
+  a.cap = ((bytes + slack) >> 20) << 20;
+  CHIP_CHECK(hipMalloc(&a.p, a.cap));
+  return a.p;
 }
+}  // namespace
+
+void* workspace(size_t bytes) { return arena_get(0, bytes, size_t(1) << 22); }
 
 // Second, independent arena: the dgrad filter images live here while the same call may take
 // split-K slabs from workspace() (two simultaneous users must not share one base pointer).
-void* workspace_aux(size_t bytes) {
-  static void* ws = nullptr;
-  static size_t cap = 0;
-  if (bytes <= cap) return ws;
-  CHIP_CHECK(hipStreamSynchronize(g_stream));
-  if (ws) CHIP_CHECK(hipFree(ws));
-  cap = ((bytes + (size_t(1) << 20)) >> 20) << 20;
-  CHIP_CHECK(hipMalloc(&ws, cap));
-  return ws;
-}
+void* workspace_aux(size_t bytes) { return arena_get(1, bytes, size_t(1) << 20); }
 
 const float* zero_page() {
   static float* z = nullptr;
@@ -122,11 +123,11 @@ int convnet_hip_init(int device_id) {
 }
 
 void convnet_hip_shutdown(void) {
-  if (g_ws) {
-    hipStreamSynchronize(g_stream);
-    hipFree(g_ws);
-    g_ws = nullptr;
-    g_ws_bytes = 0;
+  hipDeviceSynchronize();
+  for (auto& per_stream : g_arena) {
+    for (auto& kv : per_stream)
+      if (kv.second.p) hipFree(kv.second.p);
+    per_stream.clear();
   }
 }
 

@@ -119,6 +119,15 @@ class GradientExchange:
                     t.div_(self.world_)
             self.done_events_[i] = None
 
+    def BucketState(self, edge):
+        """"pending" while the edge's bucket has not been handed to RCCL yet; afterwards the event that
+        fires when its all-reduce is complete (None if the exchange ran synchronously or the edge has no
+        slice).  Non-consuming: several edges of one bucket may wait on the same event from another stream."""
+        i = self.bucket_of_.get(edge)
+        if i is None:
+            return None
+        return self.done_events_.get(i, "pending")
+
     def WaitFor(self, edge):
         i = self.bucket_of_.get(edge)
         if i is None:

@@ -9,6 +9,7 @@ All arithmetic happens in the HIP library through its C ABI; there is no torch o
 Errors follow the reference: a non-zero ABI code prints ``GetStringError`` and raises
 (``cerr << ...; exit(1)`` in src/matrix.cc:175-179 — here ``MatrixError`` so tests can see it).
 """
+import contextlib
 import ctypes
 
 import numpy as np
@@ -58,6 +59,20 @@ class Matrix:
     def UseCurrentStream():
         """Route library launches to torch's current stream (the reference used stream 0)."""
         lib.convnet_hip_set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    @staticmethod
+    @contextlib.contextmanager
+    def OnStream(stream):
+        """Launch the library calls made inside the block on ``stream`` (a torch.cuda.Stream) — the reference's
+        cross-GPU ordering tools (cuda_record_event / StreamWaitEvent, cudamat.cu:65-81) applied to a second
+        stream of one GPU.  The library keeps separate scratch arenas per stream."""
+        prev = lib.convnet_hip_get_stream()
+        lib.convnet_hip_set_stream(ctypes.c_void_p(stream.cuda_stream))
+        try:
+            with torch.cuda.stream(stream):
+                yield
+        finally:
+            lib.convnet_hip_set_stream(ctypes.c_void_p(prev))
 
     @staticmethod
     def SetDevice(gpu_id):

@@ -218,3 +218,32 @@ def test_training_fits_a_fixed_batch_and_dropout_net_stays_finite(gpu):
         drop.TrainOneBatch()
     assert np.isfinite(drop.parameters_.ToNumpy()).all()
     assert 0 <= drop.ReadCorrectCount() <= 20 * N
+
+
+@pytest.mark.gpu
+def test_side_stream_updates_are_bit_identical_to_serial_updates(gpu):
+    """overlap_update enqueues each edge's optimizer step on a second stream during Bprop; weights, momentum
+    history and gradients after several steps must equal the serial UpdateWeights run bit for bit (dropout off:
+    the RNG stream is shared state)."""
+    from convnet_amd.convnet import ConvNet
+    from convnet_amd.datahandler import SyntheticDataHandler
+    nets = []
+    for overlap in (False, True):
+        net = ConvNet(small_alexnet(dropprob=0.0), fused=True, overlap_update=overlap)
+        net.SetBatchsize(32)
+        net.SetupDataset(SyntheticDataHandler(net, 32, seed=11, num_batches=2))
+        net.AllocateMemory(False)
+        nets.append(net)
+    copy_params(nets[0], nets[1])
+    for _ in range(6):
+        for net in nets:
+            net.TrainOneBatch()
+    assert nets[1].side_stream_ is not None and nets[0].side_stream_ is None
+    import torch
+    torch.cuda.synchronize()
+    for name in ("parameters_", "history_", "grad_parameters_"):
+        a, b = getattr(nets[0], name).ToNumpy().reshape(-1), getattr(nets[1], name).ToNumpy().reshape(-1)
+        for (off, n), (off1, n1) in zip(nets[0].edge_slices_.values(), nets[1].edge_slices_.values()):
+            assert (off, n) == (off1, n1)   # the 128-float padding between slices is never written: skip it
+            bad = np.flatnonzero(a[off:off + n] != b[off:off + n])
+            assert bad.size == 0, (name, off, bad.size, bad[:8].tolist())

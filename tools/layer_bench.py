@@ -30,7 +30,14 @@ def main():
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--vgg", action="store_true", help="VGG-16 conv shapes (3x3 s1 p1) instead of AlexNet's")
     args = ap.parse_args()
+    if args.vgg:
+        CONVS.clear()
+        FCS.clear()
+        for i, (C, H, F) in enumerate([(3, 224, 64), (64, 224, 64), (64, 112, 128), (128, 112, 128), (128, 56, 256), (256, 56, 256),
+                                       (256, 28, 512), (512, 28, 512), (512, 14, 512)]):
+            CONVS[f"v{i}_{C}x{H}"] = (C, H, F, 3, 1, 1)
     Matrix.SetupCUDADevice(0)
     N = args.n
     rows = []
