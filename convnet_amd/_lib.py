@@ -87,6 +87,10 @@ def _load():
     sig("get_last_cuda_error", ctypes.c_char_p)
     sig("cuda_set_device", I, I)
     sig("cuda_sync_threads", None)
+    for ev_fn in ("cuda_create_event", "cuda_record_event", "cuda_synchronize_event"):
+        sig(ev_fn, I, P(ctypes.c_void_p))
+    sig("cublas_init", I)
+    sig("cublas_shutdown", I)
     sig("convnet_hip_last_kernel_info", None, P(KernelInfo))
     sig("convnet_hip_profile_enable", None, I)
     sig("convnet_hip_profile_report", ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t)

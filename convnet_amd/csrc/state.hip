@@ -1,5 +1,6 @@
 // Library state, memory plumbing and views: the non-compute part of the cudamat ABI
 // (reference cudamat/cudamat.cu:40-160,360-640), re-done over the HIP runtime.
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <string>
@@ -145,6 +146,22 @@ const char* get_last_cuda_error(void) { return g_last_error.c_str(); }
 int cuda_set_device(int deviceId) { return hipSetDevice(deviceId) == hipSuccess ? 0 : CUDA_ERROR; }
 
 void cuda_sync_threads(void) { CHIP_CHECK(hipStreamSynchronize(g_stream)); }
+
+static int event_status(hipError_t err) {
+  if (err != hipSuccess) {
+    set_last_error(hipGetErrorString(err));
+    printf("%s\n", hipGetErrorString(err));
+  }
+  return err != hipSuccess;
+}
+int cuda_create_event(void** t) { return event_status(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(t), hipEventDisableTiming)); }
+int cuda_record_event(void** t) { return event_status(hipEventRecord(*reinterpret_cast<hipEvent_t*>(t), g_stream)); }
+int cuda_synchronize_event(void** t) { return event_status(hipStreamWaitEvent(g_stream, *reinterpret_cast<hipEvent_t*>(t), 0)); }
+int cublas_init(void) { return 0; }
+int cublas_shutdown(void) {
+  convnet_hip_shutdown();
+  return 0;
+}
 
 void convnet_hip_last_kernel_info(ConvnetHipKernelInfo* out) { *out = g_info; }
 

@@ -124,6 +124,18 @@ class Matrix:
         self.mat_.data_host = self._host.ctypes.data_as(_lib.c_float_p)
         self.mat_.on_host = 1
 
+    def SetReady(self):
+        """Matrix::SetReady (src/matrix.cc:607-617): record this matrix's event on the current stream."""
+        if getattr(self, "_ready", None) is None:
+            self._ready = ctypes.c_void_p()
+            _chk(lib.cuda_create_event(ctypes.byref(self._ready)), "cuda_create_event")
+        _chk(lib.cuda_record_event(ctypes.byref(self._ready)), "cuda_record_event")
+
+    def WaitTillReady(self):
+        """Matrix::WaitTillReady (src/matrix.cc:619-631): the current stream (not the host) waits for SetReady."""
+        if getattr(self, "_ready", None) is not None:
+            _chk(lib.cuda_synchronize_event(ctypes.byref(self._ready)), "cuda_synchronize_event")
+
     def SetupTranspose(self):
         ctypes.memmove(ctypes.byref(self.mat_t_), ctypes.byref(self.mat_), ctypes.sizeof(cudamat))
         self.mat_t_.is_trans = 1 - self.mat_.is_trans

@@ -88,6 +88,15 @@ const char* convnet_hip_version(void);
 const char* get_last_cuda_error(void);               /* cudamat.cuh:109 */
 int cuda_set_device(int deviceId);                   /* cudamat.cuh:116 */
 void cuda_sync_threads(void);                        /* cudamat.cuh:123 — synchronises the current stream */
+/* Event trio the reference's Matrix::SetReady / WaitTillReady use for cross-stream ordering (cudamat.cuh:110-112,
+ * cudamat.cu:70-91).  `t` points at a hipEvent_t (an opaque pointer, spelled void* here so this header needs no HIP
+ * include).  record: on the library's current stream; synchronize: the CURRENT STREAM waits (hipStreamWaitEvent), the
+ * host does not block — exactly the reference's behaviour.  Return 0 on success, non-zero on failure. */
+int cuda_create_event(void** t);
+int cuda_record_event(void** t);
+int cuda_synchronize_event(void** t);
+int cublas_init(void);                               /* cudamat.cuh:93 — no BLAS handle here: returns 0 */
+int cublas_shutdown(void);                           /* cudamat.cuh:94 — frees the scratch arenas */
 
 /* ---- memory / views (cudamat.cuh:124-153) -------------------------------------------------------- */
 int allocate_device_memory(cudamat* mat);

@@ -265,3 +265,24 @@ def test_dropout_statistics_and_relu_dropout(hip):
     R.FillWithRand()
     r = R.ToNumpy().reshape(-1)
     assert r.min() >= 0 and r.max() < 1 and abs(r.mean() - 0.5) < 2e-3
+
+
+@pytest.mark.gpu
+def test_event_trio_orders_two_streams(hip):
+    """cuda_create_event / cuda_record_event / cuda_synchronize_event (cudamat.cu:70-91): a consumer on a second
+    stream that waits on the producer's event sees the produced values (Matrix::SetReady / WaitTillReady)."""
+    import torch
+    from convnet_amd.matrix import Matrix
+    a, b = Matrix(256, 4096), Matrix(256, 4096)
+    side = torch.cuda.Stream()
+    for k in range(5):
+        a.Set(float(k))
+        for _ in range(20):
+            a.Add(1.0)              # a long-ish chain on the main stream
+        a.SetReady()
+        with Matrix.OnStream(side):
+            a.WaitTillReady()
+            b.Set(a)                # copy on the side stream, ordered after the chain by the event only
+            b.SetReady()
+        b.WaitTillReady()           # main stream waits for the copy before reading / overwriting
+        assert float(b.Sum()) == pytest.approx((k + 20) * 256 * 4096, rel=1e-6)
