@@ -19,6 +19,7 @@
 // contiguous dimension of every activation, so it is mapped to the D *column* (lane) dimension:
 // loads of 4 consecutive images per lane are one ds_read_b128 / global dwordx4 and stores are
 // 512 contiguous bytes per half-wave.  64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak (fp32 matrix).
+#include <algorithm>
 #include <cmath>
 #include <string>
 
@@ -58,6 +59,20 @@ struct GGParams {
   float post_scale;
 };
 
+// A strided dgrad is one gather-GEMM per stride class (conv_down_impl); the classes differ only in the fields
+// below.  Passing them as a table lets ONE launch cover all classes: block b belongs to the class whose
+// [tile_end[c-1], tile_end[c]) range holds b (classes sorted by K, largest first, so the long blocks are
+// dispatched first and the short ones fill the tail).  n == 0: ordinary single-problem launch.
+struct GGClass {
+  const float* A;
+  int K, GX, G, TX, TYX, y0, x0, dy0, dx0, ncols, col_tiles, tile_end;
+};
+constexpr int kMaxClasses = 16;
+struct GGClassTable {
+  int n;
+  GGClass c[kMaxClasses];
+};
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
@@ -72,7 +87,7 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
 // CW = images per wave-column (128: 4 interleaved 32-image MFMA column tiles per wave, ds_read_b128;
 // 64: 2 tiles, ds_read_b64 — used with MT=3 so a 96-row problem (conv1 fprop, conv2 dgrad) fills its tile).
 template <int WR, int WC, int MT, int CW, bool A_KCONTIG, bool VEC>
-__global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg_kernel(const GGParams p) {
+__global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg_kernel(const GGParams pin, const GGClassTable ct) {
   constexpr int NT = WR * WC * 64;
   constexpr int NTC = CW / 32, CW4 = CW / 4;
   using fvec = __attribute__((ext_vector_type(NTC))) float;
@@ -86,10 +101,23 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
   float* As = smem;                 // [2][A_STAGE]
   float* Bs = smem + 2 * A_STAGE;   // [2][B_STAGE]
 
-  const int tiles = p.row_tiles * p.col_tiles;
-  const int per = (tiles + 7) >> 3;
-  const int L = xcd_remap(blockIdx.x, tiles);
-  if (L >= tiles || (int)blockIdx.x >= per * 8) return;
+  GGParams p = pin;
+  int L;
+  if (ct.n > 0) {
+    const int b = blockIdx.x;
+    if (b >= ct.c[ct.n - 1].tile_end) return;
+    int c = 0;
+    while (b >= ct.c[c].tile_end) ++c;
+    L = b - (c > 0 ? ct.c[c - 1].tile_end : 0);
+    const GGClass& k = ct.c[c];
+    p.A = k.A; p.K = k.K; p.GX = k.GX; p.G = k.G; p.TX = k.TX; p.TYX = k.TYX;
+    p.y0 = k.y0; p.x0 = k.x0; p.dy0 = k.dy0; p.dx0 = k.dx0; p.ncols = k.ncols; p.col_tiles = k.col_tiles;
+  } else {
+    const int tiles = p.row_tiles * p.col_tiles;
+    const int per = (tiles + 7) >> 3;
+    L = xcd_remap(blockIdx.x, tiles);
+    if (L >= tiles || (int)blockIdx.x >= per * 8) return;
+  }
   const int row_tile = L % p.row_tiles, col_tile = L / p.row_tiles;
   const int split = blockIdx.y;
 
@@ -742,6 +770,42 @@ void allow_big_lds(Kern kern, size_t lds) {
 
 // Launch one gather-GEMM.  `dst_elems` > 0 means the launch covers the whole destination matrix,
 // which makes a split-K (slab per split + deterministic reduce) legal.
+static const GGClassTable kNoClasses = {};
+
+// One launch over every stride class of a strided dgrad.  `cls` carries A, K, GX, G, TX, TYX, y0, x0, dy0, dx0
+// per class; ncols / col_tiles / tile_end are filled here for the chosen tile shape.
+template <int WR, int WC, int MT, int CW>
+void gg_launch_classes(GGParams& p, GGClassTable& ct, bool vec) {
+  constexpr int ROWS = WR * MT * 32;
+  constexpr int A_STAGE = BK * ROWS, B_STAGE = WC * BK * CW;
+  const size_t lds = sizeof(float) * 2 * (A_STAGE + B_STAGE);
+  p.nblk = divup(p.N, CW);
+  p.row_tiles = divup(p.R, ROWS);
+  p.zero = zero_page();
+  p.splits = 1;
+  p.chunks_per_split = 1 << 24;
+  p.partial = nullptr;
+  p.slab = 0;
+  std::sort(ct.c, ct.c + ct.n, [](const GGClass& a, const GGClass& b) { return a.K > b.K; });
+  int end = 0;
+  for (int i = 0; i < ct.n; ++i) {
+    ct.c[i].ncols = ct.c[i].G * p.nblk;
+    ct.c[i].col_tiles = divup(ct.c[i].ncols, WC);
+    end += p.row_tiles * ct.c[i].col_tiles;
+    ct.c[i].tile_end = end;
+  }
+  static const std::string kname = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ",rc>";
+  KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0);
+  dim3 grid(end), block(WR * WC * 64);
+  if (vec) {
+    allow_big_lds(gg_kernel<WR, WC, MT, CW, false, true>, lds);
+    hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, false, true>), grid, block, lds, stream(), p, ct);
+  } else {
+    allow_big_lds(gg_kernel<WR, WC, MT, CW, false, false>, lds);
+    hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, false, false>), grid, block, lds, stream(), p, ct);
+  }
+}
+
 template <int WR, int WC, int MT, int CW, bool AK>
 void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   constexpr int ROWS = WR * MT * 32;
@@ -787,10 +851,10 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
     KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0);
     if (vec) {
       allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, true>, lds);
-      hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, true>), grid, block, lds, stream(), p);
+      hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, true>), grid, block, lds, stream(), p, kNoClasses);
     } else {
       allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, false>, lds);
-      hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, false>), grid, block, lds, stream(), p);
+      hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, false>), grid, block, lds, stream(), p, kNoClasses);
     }
   }
   if (splits > 1) {
@@ -817,6 +881,17 @@ void gg_run(GGParams& p, bool vec, size_t dst_elems) {
     gg_launch_cfg<2, 2, 1, 128, AK>(p, vec, dst_elems);
   else
     gg_launch_cfg<1, 4, 1, 128, AK>(p, vec, dst_elems);
+}
+
+void gg_run_classes(GGParams& p, GGClassTable& ct, bool vec) {   // same tile choice as gg_run
+  if (p.R > 96 || (p.R > 64 && p.R <= 96 && (!vec)))
+    gg_launch_classes<2, 2, 2, 128>(p, ct, vec);
+  else if (p.R > 64)
+    gg_launch_classes<1, 4, 3, 64>(p, ct, vec);
+  else if (p.R > 32)
+    gg_launch_classes<2, 2, 1, 128>(p, ct, vec);
+  else
+    gg_launch_classes<1, 4, 1, 128>(p, ct, vec);
 }
 
 template <int WM, int WN, int MT, int NTL>
@@ -972,6 +1047,17 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
   size_t woff = 0;
   double flops = 0;
   int blocks = 0;
+  GGParams base{};
+  base.src = derivs->data_device; base.dst = targets->data_device; base.bias = nullptr;
+  base.R = g.C; base.N = g.N; base.lda = g.C;
+  base.SH = g.My; base.SW = g.Mx; base.ssy = 1; base.ssx = 1; base.dir = -1;
+  base.DW = g.W; base.DP = g.H * g.W; base.dsy = g.sy; base.dsx = g.sx;
+  base.scaleTargets = scaleTargets; base.relu = 0;
+  base.mask = mask ? mask->data_device : nullptr; base.post_scale = post_scale;
+  const bool vec = g.N % 4 == 0 && g.C % 4 == 0 && aligned16(base.src) && aligned16(base.dst) && aligned16(base.mask);
+  GGClassTable ct{};
+  const bool multi = g.sy * g.sx > 1 && g.sy * g.sx <= kMaxClasses;   // all classes in one launch (no wave-quantisation per class)
+  t_op = "conv_dgrad";
   for (int cy = 0; cy < g.sy; ++cy) {
     for (int cx = 0; cx < g.sx; ++cx) {
       const int TYc = cy < g.Ky ? divup(g.Ky - cy, g.sy) : 0;
@@ -995,24 +1081,30 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
         hipLaunchKernelGGL(dgrad_filter_kernel, dim3(nb), dim3(256), 0, stream(), filters->data_device, wc, g.F, g.C, g.Ky,
                            g.Kx, cy, cx, g.sy, g.sx, TYc, TXc);
       }
-      GGParams p{};
-      p.A = wc; p.src = derivs->data_device; p.dst = targets->data_device; p.bias = nullptr;
-      p.R = g.C; p.K = g.F * TYc * TXc; p.N = g.N; p.lda = g.C;
-      p.GX = GX; p.G = GY * GX; p.TX = TXc > 0 ? TXc : 1; p.TYX = TYc * TXc > 0 ? TYc * TXc : 1;
-      p.SH = g.My; p.SW = g.Mx; p.ssy = 1; p.ssx = 1; p.y0 = jy0; p.x0 = jx0; p.dir = -1;
-      p.DW = g.W; p.DP = g.H * g.W; p.dsy = g.sy; p.dsx = g.sx; p.dy0 = iy0; p.dx0 = ix0;
-      p.nblk = divup(g.N, 128); p.ncols = p.G * p.nblk;
-      p.scaleTargets = scaleTargets; p.relu = 0;
-      p.mask = mask ? mask->data_device : nullptr; p.post_scale = post_scale;
-      const bool vec = g.N % 4 == 0 && g.C % 4 == 0 && aligned16(p.src) && aligned16(p.dst) && aligned16(p.mask);
-      t_op = "conv_dgrad";
-      t_flops = 2.0 * g.N * p.G * (double)g.C * p.K;
+      GGClass k{};
+      k.A = wc; k.K = g.F * TYc * TXc;
+      k.GX = GX; k.G = GY * GX; k.TX = TXc > 0 ? TXc : 1; k.TYX = TYc * TXc > 0 ? TYc * TXc : 1;
+      k.y0 = jy0; k.x0 = jx0; k.dy0 = iy0; k.dx0 = ix0;
+      const double cflops = 2.0 * g.N * k.G * (double)g.C * k.K;
+      flops += cflops;
+      if (multi) {
+        ct.c[ct.n++] = k;
+        continue;
+      }
+      GGParams p = base;
+      p.A = k.A; p.K = k.K; p.GX = k.GX; p.G = k.G; p.TX = k.TX; p.TYX = k.TYX;
+      p.y0 = k.y0; p.x0 = k.x0; p.dy0 = k.dy0; p.dx0 = k.dx0;
+      t_flops = cflops;
       // a stride-1 convolution has a single class that owns every input pixel: split-K is legal there
       const bool whole = g.sy == 1 && g.sx == 1 && GY == g.H && GX == g.W;
       gg_run<false>(p, vec, whole ? (size_t)g.N * g.H * g.W * g.C : 0);
-      flops += 2.0 * g.N * p.G * (double)g.C * p.K;
       blocks += p.row_tiles * p.col_tiles;
     }
+  }
+  if (multi && ct.n > 0) {
+    t_flops = flops;
+    gg_run_classes(base, ct, vec);
+    blocks = ct.c[ct.n - 1].tile_end;
   }
   note_kernel("gg_kernel(dgrad)", flops, blocks, 1);
 }
