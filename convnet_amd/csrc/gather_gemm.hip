@@ -510,11 +510,17 @@ struct WGParams {
 constexpr int WG_NB = 32;          // images per stage
 constexpr int WG_PITCH = WG_NB + 4;  // conflict-free ds_read_b128 across rows
 
-template <int WM, int WN, int MT, int NTL, bool VEC>
+// TS = MFMA tile edge: 32 (v_mfma_f32_32x32x2, 16 accumulator registers per tile) or 16 (v_mfma_f32_16x16x4, 4 per
+// tile; same FLOP/clk).  The 16-wide tiles let a 160 x 96 problem (conv1: 147 taps x 96 filters) split evenly
+// over 2x2 waves (80 x 48 each), which no arrangement of 32-wide tiles can: the 5-wave 32x32 config ran at 70
+// TFLOP/s with 10 waves on 4 SIMDs.
+template <int WM, int WN, int MT, int NTL, bool VEC, int TS>
 __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
   constexpr int NT = WM * WN * 64;
-  constexpr int KT = WM * MT * 32;   // k-columns (D rows) per block
-  constexpr int FT = WN * NTL * 32;  // filters (D cols / lanes) per block
+  constexpr int KT = WM * MT * TS;   // k-columns (D rows) per block
+  constexpr int FT = WN * NTL * TS;  // filters (D cols / lanes) per block
+  constexpr int LH = 64 / TS;        // k-groups of a wave: lane = li + TS*lh supplies k index lh of each MFMA
+  using facc = __attribute__((ext_vector_type(TS == 32 ? 16 : 4))) float;
   constexpr int A_STAGE = KT * WG_PITCH, B_STAGE = FT * WG_PITCH;
   constexpr int NA = (KT * 8 + NT - 1) / NT, NB = (FT * 8 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
   const int f_tile = tile_id % p.f_tiles, k_tile = tile_id / p.f_tiles;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WN, wn = wave % WN;
-  const int li = lane & 31, lh = lane >> 5;
+  const int li = lane % TS, lh = lane / TS;
   const int kc0 = k_tile * KT, f0 = f_tile * FT;
   const int N = p.N;
 
@@ -665,13 +671,13 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
       if (tid + it * NT < FT * 8) st4(bs + b_lds[it], rb[it]);
   };
 
-  f32x16 acc[MT][NTL];
+  facc acc[MT][NTL];
 #pragma unroll
   for (int t = 0; t < MT; ++t)
 #pragma unroll
     for (int u = 0; u < NTL; ++u)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+      for (int e = 0; e < (TS == 32 ? 16 : 4); ++e) acc[t][u][e] = 0.f;
 
   if (cend > cbeg) {
     fetch(cbeg);
@@ -681,22 +687,26 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
   for (int c = cbeg; c < cend; ++c) {
     const int buf = (c - cbeg) & 1;
     if (c + 1 < cend) fetch(c + 1);
-    const float* ar = As + buf * A_STAGE + (wm * MT * 32 + li) * WG_PITCH + 4 * lh;
-    const float* br = Bs + buf * B_STAGE + (wn * NTL * 32 + li) * WG_PITCH + 4 * lh;
+    const float* ar = As + buf * A_STAGE + (wm * MT * TS + li) * WG_PITCH + 4 * lh;
+    const float* br = Bs + buf * B_STAGE + (wn * NTL * TS + li) * WG_PITCH + 4 * lh;
 #pragma unroll
-    for (int q = 0; q < WG_NB / 8; ++q) {
+    for (int q = 0; q < WG_NB / (4 * LH); ++q) {   // one b128 per lane = 4*LH images of the stage
       f32x4 a4[MT], b4[NTL];
 #pragma unroll
-      for (int t = 0; t < MT; ++t) a4[t] = ld4(ar + t * 32 * WG_PITCH + 8 * q);
+      for (int t = 0; t < MT; ++t) a4[t] = ld4(ar + t * TS * WG_PITCH + 4 * LH * q);
 #pragma unroll
-      for (int u = 0; u < NTL; ++u) b4[u] = ld4(br + u * 32 * WG_PITCH + 8 * q);
+      for (int u = 0; u < NTL; ++u) b4[u] = ld4(br + u * TS * WG_PITCH + 4 * LH * q);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
-          for (int u = 0; u < NTL; ++u)
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t][e], b4[u][e], acc[t][u], 0, 0, 0);
+          for (int u = 0; u < NTL; ++u) {
+            if constexpr (TS == 32)
+              acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t][e], b4[u][e], acc[t][u], 0, 0, 0);
+            else
+              acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t][e], b4[u][e], acc[t][u], 0, 0, 0);
+          }
     }
     if (c + 1 < cend) stash(buf ^ 1);
     __syncthreads();
@@ -706,13 +716,14 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
   float* out = fin ? p.dst : p.partial + (size_t)split * p.K * p.F;
 #pragma unroll
   for (int u = 0; u < NTL; ++u) {
-    const int f = f0 + wn * NTL * 32 + u * 32 + li;
+    const int f = f0 + (wn * NTL + u) * TS + li;
     if (f >= p.F) continue;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int k = kc0 + wm * MT * 32 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+      for (int reg = 0; reg < (TS == 32 ? 16 : 4); ++reg) {
+        // D row held by (lane group lh, register reg): 32x32: (reg&3) + 8*(reg>>2) + 4*lh; 16x16: 4*lh + reg
+        const int k = kc0 + (wm * MT + t) * TS + (TS == 32 ? (reg & 3) + 8 * (reg >> 2) + 4 * lh : 4 * lh + reg);
         if (k >= p.K) continue;
         float* dp = out + (size_t)k * p.F + f;
         float v = acc[t][u][reg];
@@ -894,9 +905,9 @@ void gg_run_classes(GGParams& p, GGClassTable& ct, bool vec) {   // same tile ch
     gg_launch_classes<1, 4, 1, 128>(p, ct, vec);
 }
 
-template <int WM, int WN, int MT, int NTL>
+template <int WM, int WN, int MT, int NTL, int TS = 32>
 void wg_launch_cfg(WGParams& p, bool vec) {
-  constexpr int KT = WM * MT * 32, FT = WN * NTL * 32;
+  constexpr int KT = WM * MT * TS, FT = WN * NTL * TS;
   const size_t lds = sizeof(float) * 2 * (KT + FT) * WG_PITCH;
   p.k_tiles = divup(p.K, KT);
   p.f_tiles = divup(p.F, FT);
@@ -921,15 +932,15 @@ void wg_launch_cfg(WGParams& p, bool vec) {
   const int groups = splits > 64 ? 32 : 1;   // two-level reduce when the slab count dwarfs the tile
   p.partial = splits > 1 ? static_cast<float*>(workspace(sizeof(float) * total * (splits + (groups > 1 ? groups : 0)))) : nullptr;
   dim3 grid(((tiles * splits + 7) / 8) * 8), block(WM * WN * 64);
-  static const std::string kname = "wg_kernel<" + std::to_string(WM) + "," + std::to_string(WN) + "," + std::to_string(MT) + "," + std::to_string(NTL) + ">";
+  static const std::string kname = "wg_kernel<" + std::to_string(WM) + "," + std::to_string(WN) + "," + std::to_string(MT) + "," + std::to_string(NTL) + (TS == 16 ? ",x16>" : ">");
   {
     KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0);
     if (vec) {
-      allow_big_lds(wg_kernel<WM, WN, MT, NTL, true>, lds);
-      hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, true>), grid, block, lds, stream(), p);
+      allow_big_lds(wg_kernel<WM, WN, MT, NTL, true, TS>, lds);
+      hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, true, TS>), grid, block, lds, stream(), p);
     } else {
-      allow_big_lds(wg_kernel<WM, WN, MT, NTL, false>, lds);
-      hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, false>), grid, block, lds, stream(), p);
+      allow_big_lds(wg_kernel<WM, WN, MT, NTL, false, TS>, lds);
+      hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, false, TS>), grid, block, lds, stream(), p);
     }
   }
   if (splits > 1) {
@@ -963,7 +974,7 @@ void wg_launch(WGParams& p, bool vec) {
   }
   const bool k160 = divup(p.K, 160) * 160 < divup(p.K, 128) * 128;
   if (ft == 128) wg_launch_cfg<2, 2, 2, 2>(p, vec);
-  else if (ft == 96 && k160) wg_launch_cfg<5, 1, 1, 3>(p, vec);
+  else if (ft == 96 && k160) wg_launch_cfg<2, 2, 5, 3, 16>(p, vec);   // 160 x 96 as 2x2 waves of 80 x 48 (16x16x4 MFMA)
   else if (ft == 96) wg_launch_cfg<4, 1, 1, 3>(p, vec);
   else if (ft == 64) wg_launch_cfg<4, 1, 1, 2>(p, vec);
   else wg_launch_cfg<4, 1, 1, 1>(p, vec);
