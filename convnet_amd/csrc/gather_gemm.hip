@@ -492,8 +492,10 @@ struct WGParams {
   const float* src;   // layer input  (N, SH*SW*C)
   const float* dout;  // output deriv (N, M*F), M = GY*GX
   float* dst;         // dW (F, K)  column-major: dst[f + F*k]
-  float* partial;     // [splits][K][F]
-  const float* zero;  // zero page for out-of-range loads
+  float* partial;     // [splits][K (+1 with bias_dst)][F]
+  const float* zero;  // zero page for out-of-range loads; floats [32, 36) of the page hold 1.0f
+  float* bias_dst;    // nullable: db (1, F).  The bias gradient is the dW row of a virtual tap k == K whose input is
+                      // the constant 1 (db[f] = sum over pixels, images of dout) — it rides in a padding row of the tile.
   int K, F, N;
   int GX, M;
   int TX, TYX;
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
   const int N = p.N;
 
   // A slots: one k-column each (fixed for the whole kernel)
-  int a_choff[NA], a_ta[NA], a_tb[NA], a_n[NA], a_lds[NA];
+  int a_choff[NA], a_ta[NA], a_tb[NA], a_n[NA], a_lds[NA], a_alt[NA];
   bool a_ok[NA];
 #pragma unroll
   for (int it = 0; it < NA; ++it) {
@@ -551,6 +553,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
     const int row = idx >> 3, c4 = idx & 7;
     const int k = kc0 + row;
     const bool ok = idx < KT * 8 && k < p.K;
+    a_alt[it] = (idx < KT * 8 && k == p.K && p.bias_dst) ? 32 : 0;   // ones for the bias row, zeros otherwise
     const int kk = ok ? k : 0;
     const int ch = kk / p.TYX, tap = kk - ch * p.TYX;
     a_ta[it] = tap / p.TX;
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const bool ok = a_ok[it] && (unsigned)(ysb + a_ta[it]) < (unsigned)p.SH && (unsigned)(xsb + a_tb[it]) < (unsigned)p.SW && nb + a_n[it] < N;
-      ra[it] = ld4(ok ? p.src + (a_const[it] + ua) : p.zero);
+      ra[it] = ld4(ok ? p.src + (a_const[it] + ua) : p.zero + a_alt[it]);
     }
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
@@ -631,7 +634,9 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       const int ys = ysb + a_ta[it], xs = xsb + a_tb[it];
       const int n = nb + a_n[it];
-      if (a_ok[it] && ys >= 0 && ys < p.SH && xs >= 0 && xs < p.SW) {
+      if (a_alt[it]) {
+        v = f32x4{1.f, 1.f, 1.f, 1.f};   // images past N meet zero dout columns
+      } else if (a_ok[it] && ys >= 0 && ys < p.SH && xs >= 0 && xs < p.SW) {
         const float* sp = p.src + ((size_t)(a_choff[it] + ys * p.SW + xs)) * N + n;
         if (VEC) {
           if (n < N) v = ld4(sp);
@@ -713,7 +718,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
   }
 
   const bool fin = p.splits == 1;
-  float* out = fin ? p.dst : p.partial + (size_t)split * p.K * p.F;
+  const int KB = p.K + (p.bias_dst ? 1 : 0);
+  float* out = fin ? p.dst : p.partial + (size_t)split * KB * p.F;
 #pragma unroll
   for (int u = 0; u < NTL; ++u) {
     const int f = f0 + (wn * NTL + u) * TS + li;
@@ -724,8 +730,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
       for (int reg = 0; reg < (TS == 32 ? 16 : 4); ++reg) {
         // D row held by (lane group lh, register reg): 32x32: (reg&3) + 8*(reg>>2) + 4*lh; 16x16: 4*lh + reg
         const int k = kc0 + (wm * MT + t) * TS + (TS == 32 ? (reg & 3) + 8 * (reg >> 2) + 4 * lh : 4 * lh + reg);
-        if (k >= p.K) continue;
-        float* dp = out + (size_t)k * p.F + f;
+        if (k >= KB) continue;
+        float* dp = (fin && k == p.K) ? p.bias_dst + f : out + (size_t)k * p.F + f;
         float v = acc[t][u][reg];
         if (fin) {
           v *= p.scaleOutput;
@@ -749,14 +755,16 @@ __global__ void wg_reduce_group_kernel(float* __restrict__ stage, const float* _
   }
 }
 
-__global__ void wg_reduce_kernel(float* __restrict__ dst, const float* __restrict__ partial, size_t total, int splits,
-                                 float scaleTargets, float scaleOutput) {
+// elements [0, main) go to dst, [main, total) to dst2 (the fused bias-gradient row; main == total without it)
+__global__ void wg_reduce_kernel(float* __restrict__ dst, float* __restrict__ dst2, const float* __restrict__ partial, size_t total,
+                                 size_t main, int splits, float scaleTargets, float scaleOutput) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += partial[(size_t)k * total + i];
     s *= scaleOutput;
-    if (scaleTargets != 0.f) s = scaleTargets * dst[i] + s;
-    dst[i] = s;
+    float* d = i < main ? dst + i : dst2 + (i - main);
+    if (scaleTargets != 0.f) s = scaleTargets * (*d) + s;
+    *d = s;
   }
 }
 
@@ -910,10 +918,11 @@ void wg_launch_cfg(WGParams& p, bool vec) {
   constexpr int KT = WM * MT * TS, FT = WN * NTL * TS;
   const size_t lds = sizeof(float) * 2 * (KT + FT) * WG_PITCH;
   p.k_tiles = divup(p.K, KT);
+  if (p.bias_dst && divup(p.K + 1, KT) != p.k_tiles) p.bias_dst = nullptr;   // no padding row to spare: caller sums separately
   p.f_tiles = divup(p.F, FT);
   p.zero = zero_page();
   const int tiles = p.k_tiles * p.f_tiles;
-  const size_t total = (size_t)p.K * p.F;
+  const size_t total = (size_t)(p.K + (p.bias_dst ? 1 : 0)) * p.F;
   // one full round of resident blocks (2 per CU): floor, not ceil — 568 blocks on 512 slots take two
   // rounds and leave the chip half empty (measured: 1.05 waves/SIMD, 46 % MFMA busy).
   int splits = 1;
@@ -956,8 +965,8 @@ void wg_launch_cfg(WGParams& p, bool vec) {
       slabs = stage;
       nslabs = divup(splits, per);
     }
-    hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream(), p.dst, slabs, total, nslabs, p.scaleTargets,
-                       p.scaleOutput);
+    hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream(), p.dst, p.bias_dst, slabs, total,
+                       (size_t)p.K * p.F, nslabs, p.scaleTargets, p.scaleOutput);
   }
 }
 
@@ -1135,10 +1144,14 @@ void convDownMask(cudamat* derivs, cudamat* filters, cudamat* state, cudamat* ta
   conv_down_impl(derivs, filters, targets, ds, fs, ts, d, scaleTargets, state, post_scale);
 }
 
-void convOutpGemm(cudamat* images, cudamat* derivs, cudamat* targets, Shape4D* is, Shape4D* ds, Shape4D* ts, ConvDesc d,
-                  float scaleTargets, float scaleOutput) {
+static void conv_outp_impl(cudamat* images, cudamat* derivs, cudamat* targets, cudamat* bias_grad, Shape4D* is, Shape4D* ds, Shape4D* ts,
+                           const ConvDesc& d, float scaleTargets, float scaleOutput) {
   const ConvGeo g = conv_geo(is, ts, ds, d, images, targets, derivs);
   WGParams p{};
+  if (bias_grad) {
+    CHIP_REQUIRE(bias_grad->on_device && (size_t)numel(bias_grad) == (size_t)g.F);
+    p.bias_dst = bias_grad->data_device;
+  }
   p.src = images->data_device; p.dout = derivs->data_device; p.dst = targets->data_device;
   p.K = g.C * g.Ky * g.Kx; p.F = g.F; p.N = g.N;
   p.GX = g.Mx; p.M = g.My * g.Mx; p.TX = g.Kx; p.TYX = g.Ky * g.Kx; p.SH = g.H; p.SW = g.W;
@@ -1150,6 +1163,25 @@ void convOutpGemm(cudamat* images, cudamat* derivs, cudamat* targets, Shape4D* i
   t_flops = 2.0 * g.N * p.M * (double)g.F * p.K;
   wg_launch(p, vec);
   note_kernel("wg_kernel(wgrad)", 2.0 * g.N * p.M * (double)g.F * p.K, p.k_tiles * p.f_tiles, p.splits);
+  if (bias_grad && !p.bias_dst) {
+    // the tile had no spare row: db = scaleTargets*db + scaleOutput * colsum over (N*M, F) view of derivs
+    cudamat view = *derivs;
+    view.size[0] = g.N * p.M;
+    view.size[1] = g.F;
+    view.is_trans = 0;
+    view.owns_data = 0;
+    CHIP_REQUIRE(sum_by_axis(&view, bias_grad, 0, scaleOutput, scaleTargets) == 0);
+  }
+}
+
+void convOutpGemm(cudamat* images, cudamat* derivs, cudamat* targets, Shape4D* is, Shape4D* ds, Shape4D* ts, ConvDesc d,
+                  float scaleTargets, float scaleOutput) {
+  conv_outp_impl(images, derivs, targets, nullptr, is, ds, ts, d, scaleTargets, scaleOutput);
+}
+
+void convOutpBias(cudamat* images, cudamat* derivs, cudamat* targets, cudamat* bias_grad, Shape4D* is, Shape4D* ds, Shape4D* ts,
+                  ConvDesc d, float scaleTargets, float scaleOutput) {
+  conv_outp_impl(images, derivs, targets, bias_grad, is, ds, ts, d, scaleTargets, scaleOutput);
 }
 
 void convOutp(cudamat* images, cudamat* derivs, cudamat* targets, Shape4D* is, Shape4D* ds, Shape4D* ts, ConvDesc d,

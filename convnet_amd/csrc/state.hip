@@ -50,6 +50,8 @@ const float* zero_page() {
   if (!z) {
     CHIP_CHECK(hipMalloc((void**)&z, 256));
     CHIP_CHECK(hipMemset(z, 0, 256));
+    const float ones[4] = {1.f, 1.f, 1.f, 1.f};   // floats [32, 36): the constant-1 input of wg_kernel's bias row
+    CHIP_CHECK(hipMemcpy(z + 32, ones, sizeof ones, hipMemcpyHostToDevice));
   }
   return z;
 }

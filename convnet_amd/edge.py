@@ -408,6 +408,11 @@ class ConvEdge(EdgeWithWeight):
         batch_size = input.GetRows()
         scale_targets = 1 if self.GetNumGradsReceived() > 0 else 0
         d = self.conv_desc_
+        if self.fused and self.shared_bias_ and not self.has_no_bias_:
+            db = self.tied_edge_.GetGradBias() if self.is_tied_ else self.grad_bias_
+            Matrix.ConvOutpBias(input, deriv_output, dw, db, d, scale_targets, self.scale_gradients_ / batch_size)
+            self.IncrementNumGradsReceived()
+            return
         Matrix.ConvOutp(input, deriv_output, dw, d, self.num_modules_y_, self.num_modules_x_, scale_targets,
                         self.scale_gradients_ / batch_size)
         if not self.has_no_bias_:

@@ -366,6 +366,13 @@ class Matrix:
         _chk(lib.dotMask(a.GetMat(), b.GetMat(), state.GetMat(), c.GetMat(), float(alpha), float(beta), float(post_scale)), "dotMask")
 
     @staticmethod
+    def ConvOutpBias(input, deriv_output, dw, db, conv_desc, scale_targets, scale_outputs):
+        """ConvOutp + the shared-bias gradient (two-step SumRows of conv_edge.cc:210-221) in one library call."""
+        lib.convOutpBias(input.GetMat(), deriv_output.GetMat(), dw.GetMat(), db.GetMat(), ctypes.byref(input.shape_),
+                         ctypes.byref(deriv_output.shape_), ctypes.byref(dw.shape_), conv_desc, float(scale_targets),
+                         float(scale_outputs))
+
+    @staticmethod
     def ConvMaxPoolUndoRelu(input, deriv_output, output, deriv_input, conv_desc, scale_targets):
         lib.MaxPoolUndoRelu(input.GetMat(), deriv_output.GetMat(), output.GetMat(), deriv_input.GetMat(),
                             ctypes.byref(input.shape_), ctypes.byref(deriv_output.shape_), conv_desc, float(scale_targets))

@@ -261,6 +261,13 @@ int dotMask(cudamat* mat1, cudamat* mat2, cudamat* state, cudamat* target, float
 void MaxPoolUndoRelu(cudamat* images, cudamat* maxGrads, cudamat* maxActs, cudamat* targets,
                      Shape4D* images_shape, Shape4D* maxGrads_shape, ConvDesc conv_desc,
                      float scaleTargets);
+/* ConvEdge::ComputeOuter (conv_edge.cc:183-221) in one call: dW as convOutpGemm AND the shared-bias gradient
+ * bias_grad(1,F) = scaleTargets*bias_grad + scaleOutput * sum over images and output pixels of derivs — the reference's
+ * two-step SumRows (:210-221).  The bias row rides as a virtual tap with constant input 1 in the weight-gradient tile
+ * when the tile has a spare row (conv1: 147 -> 148 of 160), else the library falls back to a column sum. */
+void convOutpBias(cudamat* images, cudamat* derivs, cudamat* targets, cudamat* bias_grad,
+                  Shape4D* images_shape, Shape4D* derivs_shape, Shape4D* targets_shape,
+                  ConvDesc conv_desc, float scaleTargets, float scaleOutput);
 
 /* ---- introspection for the roofline report: flops of the last MFMA launch family ----------------- */
 typedef struct ConvnetHipKernelInfo {

@@ -181,3 +181,14 @@ class HipImpl:
         grad[...] = G.ToNumpy().reshape(grad.shape)
         param[...] = W.ToNumpy().reshape(param.shape)
         history[...] = H.ToNumpy().reshape(history.shape)
+
+
+def conv_outp_bias(g, images, derivs, dw0, db0, scale_targets, scale_output):
+    """convOutpBias through the ABI: returns (dW, db)."""
+    h = HipImpl()
+    x = h._act(images, g.N, g.W, g.H, g.C)
+    dy = h._act(derivs, g.N, g.Mx, g.My, g.F)
+    t = _mat(dw0, g.F, g.K, (g.F, g.Kx, g.Ky, g.C))
+    b = _mat(db0.reshape(1, g.F), 1, g.F)
+    Matrix.ConvOutpBias(x, dy, t, b, _desc(g), scale_targets, scale_output)
+    return t.ToNumpy().reshape(g.filt_shape()), b.ToNumpy().reshape(g.F)

@@ -286,3 +286,22 @@ def test_event_trio_orders_two_streams(hip):
             b.SetReady()
         b.WaitTillReady()           # main stream waits for the copy before reading / overwriting
         assert float(b.Sum()) == pytest.approx((k + 20) * 256 * 4096, rel=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("g", [CONV_CASES[0], CONV_CASES[1], CONV_CASES[4], CONV_CASES[5], CONV_CASES[6]],
+                         ids=lambda g: f"N{g.N}C{g.C}F{g.F}K{g.K}")
+def test_conv_outp_bias_equals_outp_plus_two_step_sum(hip, g):
+    """convOutpBias = convOutp + the shared-bias gradient (conv_edge.cc:210-221), whether the bias row rides in the
+    weight-gradient tile (K+1 fits the padded tile: conv1's 147+1 <= 160) or the library falls back to a column sum
+    (K a multiple of the tile: conv3's 2304)."""
+    from hip_adapter import conv_outp_bias
+    rng = np.random.default_rng(21)
+    x, dy = rnd(rng, g.in_shape()), rnd(rng, g.out_shape())
+    so = 0.41 / g.N
+    for st in (0.0, 1.0):
+        dw0, db0 = rnd(rng, g.filt_shape()), rnd(rng, (g.F,))
+        dw, db = conv_outp_bias(g, x, dy, dw0.copy(), db0.copy(), st, so)
+        assert rel_err(dw, oracle.port.conv_outp(g, x, dy, dw0.copy(), st, so)) < TOL
+        ref_db = st * db0 + so * dy.reshape(g.F, -1).astype(np.float64).sum(axis=1)
+        assert np.allclose(db, ref_db, rtol=2e-5, atol=1e-5 * np.abs(ref_db).max()), np.abs(db - ref_db).max()
