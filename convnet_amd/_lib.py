@@ -123,7 +123,7 @@ def _load():
         sig(n, None, M, M, M, M, S, S, ConvDesc, F)
     for n in ("AvgPoolUndoGemm", "AvgPoolUndo"):
         sig(n, None, M, M, S, S, ConvDesc, F)
-    for n in ("ResponseNormCrossMapGemm", "ResponseNormCrossMap"):
+    for n in ("ResponseNormCrossMapGemm", "ResponseNormCrossMap", "ResponseNormCrossMapRelu"):
         sig(n, None, M, M, I, I, F, F, ctypes.c_bool)
     sig("ResponseNormCrossMapUndoGemm", None, M, M, M, I, I, F, F, ctypes.c_bool)
     sig("ResponseNormCrossMapUndo", None, M, M, M, M, I, I, F, F, ctypes.c_bool)

@@ -21,7 +21,7 @@ from collections import deque
 import torch
 
 from . import pbtxt
-from .edge import ConvEdge, Edge, EdgeWithWeight, FCEdge
+from .edge import ConvEdge, Edge, EdgeWithWeight, FCEdge, ResponseNormEdge
 from .layer import Layer, SoftmaxLayer
 from .matrix import Matrix
 
@@ -219,6 +219,8 @@ class ConvNet:
         e = l.incoming_edge_[0]
         if isinstance(e, ConvEdge):
             return e.has_no_bias_ or e.shared_bias_
+        if isinstance(e, ResponseNormEdge):
+            return l.is_relu       # the ReLU of an rnorm-fed layer rides in the rnorm kernel; other activations do not
         return isinstance(e, FCEdge)
 
     def Fprop(self, train):

@@ -324,16 +324,18 @@ __global__ void normlimit_cols_kernel(const float* __restrict__ mat, float* __re
 
 // ---- output layer -------------------------------------------------------------------------------------
 // "row_major" in the reference = one case per matrix ROW (eigenmat.cc:1093-1131).  A block owns 32
-// consecutive rows (128 contiguous bytes per column) and 8 column groups.
+// consecutive rows (128 contiguous bytes per column) and G = 32 column groups (1024 threads: the 256 x 1000
+// output layer is 8 blocks, so the per-lane column loop, not bandwidth, sets the time).
 struct SoftmaxOut {
   float* probs;    // may alias logits
   float* deriv;    // nullable: probs with 1 subtracted at the label, times deriv_scale
   float* correct;  // nullable: 1x1 accumulator (+= number of argmax==label rows)
 };
 
-__global__ void softmax_rows_kernel(const float* logits, const float* __restrict__ labels, SoftmaxOut o, int rows, int cols, float deriv_scale) {
-  __shared__ float red[8][33];
-  __shared__ int redi[8][33];
+template <int G>   // column groups per block: 32 rows x G lanes-groups, G*32 threads
+__global__ void __launch_bounds__(G * 32) softmax_rows_kernel(const float* logits, const float* __restrict__ labels, SoftmaxOut o, int rows, int cols, float deriv_scale) {
+  __shared__ float red[G][33];
+  __shared__ int redi[G][33];
   const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int row = blockIdx.x * 32 + r;
   const bool ok = row < rows;
@@ -341,7 +343,7 @@ __global__ void softmax_rows_kernel(const float* logits, const float* __restrict
   float mx = -FLT_MAX;
   int am = 0x7fffffff;
   if (ok)
-    for (int j = g; j < cols; j += 8) {
+    for (int j = g; j < cols; j += G) {
       const float v = logits[(size_t)j * rows + row];
       if (v > mx) { mx = v; am = j; }
     }
@@ -351,7 +353,7 @@ __global__ void softmax_rows_kernel(const float* logits, const float* __restrict
   mx = red[0][r];
   am = redi[0][r];
 #pragma unroll
-  for (int k = 1; k < 8; ++k) {
+  for (int k = 1; k < G; ++k) {
     const float v = red[k][r];
     const int a = redi[k][r];
     if (v > mx || (v == mx && a < am)) { mx = v; am = a; }
@@ -360,7 +362,7 @@ __global__ void softmax_rows_kernel(const float* logits, const float* __restrict
   // pass 2: exp and sum
   float s = 0.f;
   if (ok)
-    for (int j = g; j < cols; j += 8) {
+    for (int j = g; j < cols; j += G) {
       const size_t x = (size_t)j * rows + row;
       const float e = expf(logits[x] - mx);
       o.probs[x] = e;
@@ -370,11 +372,11 @@ __global__ void softmax_rows_kernel(const float* logits, const float* __restrict
   __syncthreads();
   s = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) s += red[k][r];
+  for (int k = 0; k < G; ++k) s += red[k][r];
   // pass 3: normalise (+ CE derivative)
   const int label = (ok && labels) ? (int)labels[row] : -1;
   if (ok)
-    for (int j = g; j < cols; j += 8) {
+    for (int j = g; j < cols; j += G) {
       const size_t x = (size_t)j * rows + row;
       const float pr = o.probs[x] / s;
       o.probs[x] = pr;
@@ -610,7 +612,7 @@ int softmax_row_major_multi(cudamat* mat, int numslices, cudamat* target) {
   if (numslices <= 0 || len % numslices != 0 || numel(target) != len) return ERROR_INCOMPATIBLE_DIMENSIONS;
   const int rows = (int)(len / numslices), cols = numslices;
   SoftmaxOut o{target->data_device, nullptr, nullptr};
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(divup(rows, 32)), dim3(256), 0, stream(), mat->data_device, nullptr, o, rows, cols, 1.0f);
+  hipLaunchKernelGGL(softmax_rows_kernel<32>, dim3(divup(rows, 32)), dim3(1024), 0, stream(), mat->data_device, nullptr, o, rows, cols, 1.0f);
   return launch_status();
 }
 int softmax_row_major(cudamat* mat, cudamat* target) { return softmax_row_major_multi(mat, mat->size[1], target); }
@@ -650,7 +652,7 @@ int softmax_ce_grad_correct(cudamat* logits, cudamat* labels, cudamat* probs, cu
   if (numel(probs) != numel(logits) || (deriv && numel(deriv) != numel(logits)) || numel(labels) != (size_t)logits->size[0])
     return ERROR_INCOMPATIBLE_DIMENSIONS;
   SoftmaxOut o{probs->data_device, deriv ? deriv->data_device : nullptr, correct_accum ? correct_accum->data_device : nullptr};
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(divup(logits->size[0], 32)), dim3(256), 0, stream(), logits->data_device, labels->data_device, o,
+  hipLaunchKernelGGL(softmax_rows_kernel<32>, dim3(divup(logits->size[0], 32)), dim3(1024), 0, stream(), logits->data_device, labels->data_device, o,
                      logits->size[0], logits->size[1], deriv_scale);
   return launch_status();
 }

@@ -241,7 +241,7 @@ __device__ __forceinline__ void win_bwd(int j, int C, int sizeF, bool blocked, i
 }
 
 __global__ void rnorm_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, size_t locs, int C, int sizeF, float addScale,
-                                 float powScale, bool blocked, bool vec, int cseg, int nseg) {
+                                 float powScale, bool blocked, bool vec, int cseg, int nseg, bool relu) {
   const size_t nq = (locs + 3) >> 2;
   for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq * nseg; q += (size_t)gridDim.x * blockDim.x) {
     const int seg = (int)(q / nq);
@@ -269,7 +269,10 @@ __global__ void rnorm_fwd_kernel(const float* __restrict__ in, float* __restrict
       const f32x4 x = ldv(in + (size_t)j * locs + l, 0, rem, vec);
       f32x4 y;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) y[t] = x[t] * powf(1.f + addScale * sum[t], -powScale);
+      for (int t = 0; t < 4; ++t) {
+        y[t] = x[t] * powf(1.f + addScale * sum[t], -powScale);
+        if (relu) y[t] = fmaxf(y[t], 0.f);
+      }
       stv(out + (size_t)j * locs + l, y, 0, rem, vec);
       ps = s;
       pe = e;
@@ -376,7 +379,7 @@ __device__ __forceinline__ void rn_stage(const float* __restrict__ g, float* __r
 
 template <int LT>
 __global__ void rnorm_fwd_lds_kernel(const float* __restrict__ in, float* __restrict__ out, size_t locs, int C, int sizeF, float addScale,
-                                     float powScale, bool blocked, bool vec) {
+                                     float powScale, bool blocked, bool vec, bool relu) {
   extern __shared__ __attribute__((aligned(16))) float rn_smem[];
   float* xs = rn_smem;   // [C][LT]
   const size_t l0 = (size_t)blockIdx.x * LT;
@@ -399,7 +402,8 @@ __global__ void rnorm_fwd_lds_kernel(const float* __restrict__ in, float* __rest
     for (int i = pe; i < e; ++i) { const float v = xs[i * LT + l]; sum += v * v; }
     // u^(-b) = exp2(-b * log2(u)), u >= 1: two quarter-rate transcendentals instead of ~100 VALU of powf
     // (the reference's own GPU path uses __powf, cudamat_conv_gemm.cu:458); relative error ~1e-6.
-    out[(size_t)j * locs + l0 + l] = xs[j * LT + l] * exp2f(-powScale * __log2f(1.f + addScale * sum));
+    const float y = xs[j * LT + l] * exp2f(-powScale * __log2f(1.f + addScale * sum));
+    out[(size_t)j * locs + l0 + l] = relu ? fmaxf(y, 0.f) : y;
     ps = s;
     pe = e;
   }
@@ -586,7 +590,7 @@ void AvgPoolUndo(cudamat* avgGrads, cudamat* targets, Shape4D* avgGrads_shape, S
   pool_undo<false>(nullptr, avgGrads, nullptr, targets, targets_shape, avgGrads_shape, d, scaleTargets);
 }
 
-void ResponseNormCrossMapGemm(cudamat* images, cudamat* targets, int numFilters, int sizeF, float addScale, float powScale, bool blocked) {
+static void rnorm_fwd_impl(cudamat* images, cudamat* targets, int numFilters, int sizeF, float addScale, float powScale, bool blocked, bool relu) {
   const size_t total = numel(images);
   CHIP_REQUIRE(numel(targets) == total && numFilters > 0 && total % numFilters == 0 && sizeF > 0);
   const size_t locs = total / numFilters;
@@ -598,16 +602,22 @@ void ResponseNormCrossMapGemm(cudamat* images, cudamat* targets, int numFilters,
     if (LT) {   // LDS-tiled, read-once/write-once
       const size_t smem = sizeof(float) * (size_t)C * LT;
       const dim3 grid((unsigned)((locs + LT - 1) / LT)), block(256);
-      if (LT == 64) hipLaunchKernelGGL(rnorm_fwd_lds_kernel<64>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec);
-      else if (LT == 32) hipLaunchKernelGGL(rnorm_fwd_lds_kernel<32>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec);
-      else hipLaunchKernelGGL(rnorm_fwd_lds_kernel<16>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec);
+      if (LT == 64) hipLaunchKernelGGL(rnorm_fwd_lds_kernel<64>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec, relu);
+      else if (LT == 32) hipLaunchKernelGGL(rnorm_fwd_lds_kernel<32>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec, relu);
+      else hipLaunchKernelGGL(rnorm_fwd_lds_kernel<16>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec, relu);
       return;
     }
   }
   int cseg, nseg;
   rnorm_segments((locs + 3) / 4, numFilters, sizeF, cseg, nseg);
   hipLaunchKernelGGL(rnorm_fwd_kernel, dim3(grid_for((locs + 3) / 4 * nseg)), dim3(256), 0, stream(), images->data_device, targets->data_device, locs,
-                     numFilters, sizeF, addScale, powScale, blocked, vec, cseg, nseg);
+                     numFilters, sizeF, addScale, powScale, blocked, vec, cseg, nseg, relu);
+}
+void ResponseNormCrossMapGemm(cudamat* images, cudamat* targets, int numFilters, int sizeF, float addScale, float powScale, bool blocked) {
+  rnorm_fwd_impl(images, targets, numFilters, sizeF, addScale, powScale, blocked, false);
+}
+void ResponseNormCrossMapRelu(cudamat* images, cudamat* targets, int numFilters, int sizeF, float addScale, float powScale, bool blocked) {
+  rnorm_fwd_impl(images, targets, numFilters, sizeF, addScale, powScale, blocked, true);
 }
 void ResponseNormCrossMap(cudamat* images, cudamat* targets, int numFilters, int sizeF, float addScale, float powScale, bool blocked) {
   ResponseNormCrossMapGemm(images, targets, numFilters, sizeF, addScale, powScale, blocked);

@@ -575,8 +575,9 @@ class ResponseNormEdge(Edge):
         self.num_filters_response_norm_ = int(np.float32(self.frac_of_filters_response_norm_) * np.float32(self.num_input_channels_))
 
     def ComputeUp(self, input, output, overwrite, train=True, fuse_relu=None):
+        # fuse_relu=True: the destination layer's ReLU (layer.cc:549) is applied by the same kernel
         Matrix.ConvResponseNormCrossMap(input, output, self.num_input_channels_, self.num_filters_response_norm_,
-                                        self.add_scale_, self.pow_scale_, self.blocked_)
+                                        self.add_scale_, self.pow_scale_, self.blocked_, relu=bool(fuse_relu))
 
     def ComputeDown(self, deriv_output, input, output, deriv_input, overwrite):
         Matrix.ConvResponseNormCrossMapUndo(deriv_output, input, output, deriv_input, self.num_input_channels_,

@@ -403,8 +403,9 @@ class Matrix:
                             conv_desc, float(scale_targets))
 
     @staticmethod
-    def ConvResponseNormCrossMap(input, output, numFilters, sizeF, addScale, powScale, blocked):
-        lib.ResponseNormCrossMapGemm(input.GetMat(), output.GetMat(), int(numFilters), int(sizeF), float(addScale), float(powScale), bool(blocked))
+    def ConvResponseNormCrossMap(input, output, numFilters, sizeF, addScale, powScale, blocked, relu=False):
+        fn = lib.ResponseNormCrossMapRelu if relu else lib.ResponseNormCrossMapGemm
+        fn(input.GetMat(), output.GetMat(), int(numFilters), int(sizeF), float(addScale), float(powScale), bool(blocked))
 
     @staticmethod
     def ConvResponseNormCrossMapUndo(outGrads, inputs, acts, targets, numFilters, sizeF, addScale, powScale, blocked):

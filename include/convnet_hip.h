@@ -261,6 +261,9 @@ int dotMask(cudamat* mat1, cudamat* mat2, cudamat* state, cudamat* target, float
 void MaxPoolUndoRelu(cudamat* images, cudamat* maxGrads, cudamat* maxActs, cudamat* targets,
                      Shape4D* images_shape, Shape4D* maxGrads_shape, ConvDesc conv_desc,
                      float scaleTargets);
+/* ResponseNormEdge::ComputeUp + the ReLU of a RECTIFIED_LINEAR destination layer (layer.cc:549) in one pass. */
+void ResponseNormCrossMapRelu(cudamat* images, cudamat* targets, int numFilters, int sizeF,
+                              float addScale, float powScale, bool blocked);
 /* ConvEdge::ComputeOuter (conv_edge.cc:183-221) in one call: dW as convOutpGemm AND the shared-bias gradient
  * bias_grad(1,F) = scaleTargets*bias_grad + scaleOutput * sum over images and output pixels of derivs — the reference's
  * two-step SumRows (:210-221).  The bias row rides as a virtual tap with constant input 1 in the weight-gradient tile
