@@ -266,6 +266,41 @@ __global__ void rows_sq_kernel(float* __restrict__ g, float* __restrict__ w, flo
   partial[(size_t)blockIdx.y * rows + r] = s;
 }
 
+// rows % 4 == 0 and 16-byte aligned bases: a lane owns 4 consecutive rows (one float4 per tensor per column),
+// two columns in flight, so each lane keeps 6 independent 16-byte loads outstanding instead of 3 scalar ones.
+template <bool DO_SGD>
+__global__ void rows_sq4_kernel(float* __restrict__ g, float* __restrict__ w, float* __restrict__ h, int rows, int cols, int chunk,
+                                float* __restrict__ partial, float l2, float clip, float eps, float mom) {
+  const int r = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+  if (r >= rows) return;
+  const int c0 = blockIdx.y * chunk, c1 = min(cols, c0 + chunk);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  auto one = [&](int c) {
+    const size_t i = (size_t)r + (size_t)rows * c;
+    f32x4 wv = *reinterpret_cast<f32x4*>(w + i);
+    if (DO_SGD) {
+      f32x4 gv = *reinterpret_cast<f32x4*>(g + i), hv = *reinterpret_cast<f32x4*>(h + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = gv[e], b = wv[e], d = hv[e];
+        sgd_one(a, b, d, l2, clip, eps, mom);
+        gv[e] = a; wv[e] = b; hv[e] = d;
+      }
+      *reinterpret_cast<f32x4*>(g + i) = gv;
+      *reinterpret_cast<f32x4*>(h + i) = hv;
+      *reinterpret_cast<f32x4*>(w + i) = wv;
+    }
+    s += wv * wv;
+  };
+  int c = c0;
+  for (; c + 1 < c1; c += 2) {
+    one(c);
+    one(c + 1);
+  }
+  if (c < c1) one(c);
+  *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.y * rows + r) = s;
+}
+
 __global__ void row_factor_kernel(const float* __restrict__ partial, int nchunks, int rows, float norm, int constraint, float* __restrict__ factor) {
   // block = 64 rows x 4 chunk lanes; lane q sums chunks q, q+4, ... then the 4 partials combine in fixed order
   __shared__ float sh[4][64];
@@ -302,7 +337,14 @@ inline int rows_normlimit(float* g, float* w_in, float* w_out, float* h, int row
   float* partial = static_cast<float*>(workspace(sizeof(float) * ((size_t)nchunks * rows + rows)));
   float* factor = partial + (size_t)nchunks * rows;
   dim3 grid(divup(rows, 256), nchunks);
-  if (do_sgd)
+  const bool v4 = (rows & 3) == 0 && al16(w_in) && (!do_sgd || (al16(g) && al16(h)));
+  if (v4) {
+    const dim3 g4(divup(rows / 4, 64), nchunks);
+    if (do_sgd)
+      hipLaunchKernelGGL(rows_sq4_kernel<true>, g4, dim3(64), 0, stream(), g, w_in, h, rows, cols, chunk, partial, l2, clip, eps, mom);
+    else
+      hipLaunchKernelGGL(rows_sq4_kernel<false>, g4, dim3(64), 0, stream(), nullptr, w_in, nullptr, rows, cols, chunk, partial, 0.f, 0.f, 0.f, 0.f);
+  } else if (do_sgd)
     hipLaunchKernelGGL(rows_sq_kernel<true>, grid, dim3(256), 0, stream(), g, w_in, h, rows, cols, chunk, partial, l2, clip, eps, mom);
   else
     hipLaunchKernelGGL(rows_sq_kernel<false>, grid, dim3(256), 0, stream(), nullptr, w_in, nullptr, rows, cols, chunk, partial, 0.f, 0.f, 0.f, 0.f);
