@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <string>
+#include <type_traits>
 
 #include "common.h"
 
@@ -74,6 +75,15 @@ struct GGClassTable {
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// compile-time loop: f(integral_constant<int, I>) for I in [B, E) — keeps register-array indices constant
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // XCD-aware block -> tile map: hardware places block b on XCD b%8 (observed; speed only).  Give
@@ -101,7 +111,11 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
   float* As = smem;                 // [2][A_STAGE]
   float* Bs = smem + 2 * A_STAGE;   // [2][B_STAGE]
 
-  GGParams p = pin;
+  // fields a stride class overrides live in scalars; everything else is read from the kernarg struct in place
+  const GGParams& p = pin;
+  const float* pA = p.A;
+  int pK = p.K, pGX = p.GX, pG = p.G, pTX = p.TX, pTYX = p.TYX, py0 = p.y0, px0 = p.x0, pdy0 = p.dy0, pdx0 = p.dx0, pncols = p.ncols,
+      pcol_tiles = p.col_tiles;
   int L;
   if (ct.n > 0) {
     const int b = blockIdx.x;
@@ -110,14 +124,15 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
     while (b >= ct.c[c].tile_end) ++c;
     L = b - (c > 0 ? ct.c[c - 1].tile_end : 0);
     const GGClass& k = ct.c[c];
-    p.A = k.A; p.K = k.K; p.GX = k.GX; p.G = k.G; p.TX = k.TX; p.TYX = k.TYX;
-    p.y0 = k.y0; p.x0 = k.x0; p.dy0 = k.dy0; p.dx0 = k.dx0; p.ncols = k.ncols; p.col_tiles = k.col_tiles;
+    pA = k.A; pK = k.K; pGX = k.GX; pG = k.G; pTX = k.TX; pTYX = k.TYX;
+    py0 = k.y0; px0 = k.x0; pdy0 = k.dy0; pdx0 = k.dx0; pncols = k.ncols; pcol_tiles = k.col_tiles;
   } else {
-    const int tiles = p.row_tiles * p.col_tiles;
+    const int tiles = p.row_tiles * pcol_tiles;
     const int per = (tiles + 7) >> 3;
     L = xcd_remap(blockIdx.x, tiles);
     if (L >= tiles || (int)blockIdx.x >= per * 8) return;
   }
+  (void)pG;
   const int row_tile = L % p.row_tiles, col_tile = L / p.row_tiles;
   const int split = blockIdx.y;
 
@@ -136,11 +151,11 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
     const int idx = tid + it * NT;
     const int wcol = idx / (BK * CW4), krow = (idx / CW4) % BK, c4 = idx % CW4;
     const int colid = col_tile * WC + wcol;
-    const bool ok = idx < WC * BK * CW4 && colid < p.ncols;
+    const bool ok = idx < WC * BK * CW4 && colid < pncols;
     const int m = ok ? colid / p.nblk : 0, blk = ok ? colid % p.nblk : 0;
-    const int oy = m / p.GX, ox = m - oy * p.GX;
-    b_ys0[it] = oy * p.ssy + p.y0;
-    b_xs0[it] = ox * p.ssx + p.x0;
+    const int oy = m / pGX, ox = m - oy * pGX;
+    b_ys0[it] = oy * p.ssy + py0;
+    b_xs0[it] = ox * p.ssx + px0;
     b_n[it] = blk * CW + 4 * c4;
     b_ok[it] = ok;
     b_krow[it] = krow;
@@ -149,7 +164,7 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
 
   const int kbeg = split * p.chunks_per_split * BK;
   int kend = kbeg + p.chunks_per_split * BK;
-  if (kend > p.K) kend = p.K;
+  if (kend > pK) kend = pK;
   const int nchunks = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
 
   f32x4 ra[NA], rb[NB];
@@ -159,9 +174,9 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
   // a slot's k is carried from chunk to chunk (k advances by BK = dch*TYX + da*TX + db each chunk,
   // one conditional carry per digit) instead of being re-divided, and out-of-range taps / rows /
   // images read a 16-byte zero page instead of branching.  ~25 VALU per slot per chunk.
-  const int TYn = p.TYX / p.TX;
-  const int dch = BK / p.TYX, drem = BK - dch * p.TYX;
-  const int da = drem / p.TX, db = drem - da * p.TX;
+  const int TYn = pTYX / pTX;
+  const int dch = BK / pTYX, drem = BK - dch * pTYX;
+  const int da = drem / pTX, db = drem - da * pTX;
   int s_k[NB], s_ch[NB], s_a[NB], s_b[NB];
   const float* a_ptr[NA];
   int a_k[NA];
@@ -170,11 +185,11 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
       const int k = kbeg + b_krow[it];
-      const int ch = k / p.TYX, tap = k - ch * p.TYX;
+      const int ch = k / pTYX, tap = k - ch * pTYX;
       s_k[it] = k;
       s_ch[it] = ch;
-      s_a[it] = tap / p.TX;
-      s_b[it] = tap - s_a[it] * p.TX;
+      s_a[it] = tap / pTX;
+      s_b[it] = tap - s_a[it] * pTX;
       b_ok[it] = b_ok[it] && b_n[it] < N;
     }
 #pragma unroll
@@ -185,13 +200,13 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
         const int r = r0 + 4 * c4;
         a_k[it] = kbeg + krow;
         a_ok[it] = idx < BK * (ROWS / 4) && r < p.R;
-        a_ptr[it] = p.A + (size_t)p.lda * a_k[it] + r;
+        a_ptr[it] = pA + (size_t)p.lda * a_k[it] + r;
       } else {
         const int row = idx / (BK / 4), c4 = idx % (BK / 4);
         const int r = r0 + row;
         a_k[it] = kbeg + 4 * c4;
         a_ok[it] = idx < ROWS * (BK / 4) && r < p.R;
-        a_ptr[it] = p.A + (size_t)p.lda * (a_ok[it] ? r : 0) + a_k[it];
+        a_ptr[it] = pA + (size_t)p.lda * (a_ok[it] ? r : 0) + a_k[it];
       }
     }
   }
@@ -205,41 +220,49 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
   typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
   constexpr bool GLDS_A = VEC && !A_KCONTIG, GLDS_B = VEC;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  auto fetch_vec = [&](int buf) {
-#pragma unroll
-    for (int it = 0; it < NA; ++it) {
-      const bool ok = a_ok[it] && a_k[it] < kend;
-      const float* src = ok ? a_ptr[it] : p.zero;
-      if (GLDS_A) {
-        if (tid + it * NT < BK * (ROWS / 4))
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(As + buf * A_STAGE + 4 * (64 * wave_u + it * NT)), 16, 0, 0);
-      } else {
-        ra[it] = ld4(src);
-      }
-      a_k[it] += BK;
-      a_ptr[it] += A_KCONTIG ? (size_t)BK : (size_t)p.lda * BK;
+  // one staging slot each (it must be a compile-time constant after unrolling: the slot state lives in registers)
+  // scalars for the staging lambdas (they capture these, not the parameter struct)
+  const float* const q_zero = p.zero;
+  const float* const q_src = p.src;
+  const int q_lda = p.lda, q_dir = p.dir, q_SH = p.SH, q_SW = p.SW;
+  auto fetch_a_piece = [&](auto IT, int buf) __attribute__((always_inline)) {
+    constexpr int it = decltype(IT)::value;
+    const bool ok = a_ok[it] && a_k[it] < kend;
+    const float* const ap = a_ptr[it];   // rvalues: a conditional on two lvalues selects an ADDRESS and keeps both in memory
+    const float* src = ok ? ap + 0 : q_zero + 0;
+    if (GLDS_A) {
+      if (tid + it * NT < BK * (ROWS / 4))
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(As + buf * A_STAGE + 4 * (64 * wave_u + it * NT)), 16, 0, 0);
+    } else {
+      ra[it] = ld4(src);
     }
-#pragma unroll
-    for (int it = 0; it < NB; ++it) {
-      const int ys = b_ys0[it] + p.dir * s_a[it], xs = b_xs0[it] + p.dir * s_b[it];
-      const bool ok = b_ok[it] && s_k[it] < kend && (unsigned)ys < (unsigned)p.SH && (unsigned)xs < (unsigned)p.SW;
-      const unsigned off = (unsigned)((s_ch[it] * p.SH + ys) * p.SW + xs) * (unsigned)N + (unsigned)b_n[it];
-      const float* src = ok ? p.src + off : p.zero;
-      if (GLDS_B) {
-        if (tid + it * NT < WC * BK * CW4)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(Bs + buf * B_STAGE + 4 * (64 * wave_u + it * NT)), 16, 0, 0);
-      } else {
-        rb[it] = ld4(src);
-      }
-      s_k[it] += BK;
-      int b = s_b[it] + db, a = s_a[it] + da, ch = s_ch[it] + dch;
-      if (b >= p.TX) { b -= p.TX; a += 1; }
-      if (a >= TYn) { a -= TYn; ch += 1; }
-      s_b[it] = b; s_a[it] = a; s_ch[it] = ch;
+    a_k[it] += BK;
+    a_ptr[it] += A_KCONTIG ? (size_t)BK : (size_t)q_lda * BK;
+  };
+  auto fetch_b_piece = [&](auto IT, int buf) __attribute__((always_inline)) {
+    constexpr int it = decltype(IT)::value;
+    const int ys = b_ys0[it] + q_dir * s_a[it], xs = b_xs0[it] + q_dir * s_b[it];
+    const bool ok = b_ok[it] && s_k[it] < kend && (unsigned)ys < (unsigned)q_SH && (unsigned)xs < (unsigned)q_SW;
+    const unsigned off = (unsigned)((s_ch[it] * q_SH + ys) * q_SW + xs) * (unsigned)N + (unsigned)b_n[it];
+    const float* src = ok ? q_src + off : q_zero;
+    if (GLDS_B) {
+      if (tid + it * NT < WC * BK * CW4)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(Bs + buf * B_STAGE + 4 * (64 * wave_u + it * NT)), 16, 0, 0);
+    } else {
+      rb[it] = ld4(src);
     }
+    s_k[it] += BK;
+    int b = s_b[it] + db, a = s_a[it] + da, ch = s_ch[it] + dch;
+    if (b >= pTX) { b -= pTX; a += 1; }
+    if (a >= TYn) { a -= TYn; ch += 1; }
+    s_b[it] = b; s_a[it] = a; s_ch[it] = ch;
+  };
+  auto fetch_vec = [&](int buf) __attribute__((always_inline)) {
+    static_for<0, NA>([&](auto IT) __attribute__((always_inline)) { fetch_a_piece(IT, buf); });
+    static_for<0, NB>([&](auto IT) __attribute__((always_inline)) { fetch_b_piece(IT, buf); });
   };
 
-  auto fetch = [&](int k0, int buf) {
+  auto fetch = [&](int k0, int buf) __attribute__((always_inline)) {
     if (VEC) {
       fetch_vec(buf);   // stateful: called with k0 = kbeg, kbeg+BK, ... in order
       return;
@@ -252,7 +275,7 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
         const int krow = idx / (ROWS / 4), c4 = idx % (ROWS / 4);
         const int k = k0 + krow, r = r0 + 4 * c4;
         if (idx < BK * (ROWS / 4) && k < kend) {
-          const float* ap = p.A + (size_t)p.lda * k + r;
+          const float* ap = pA + (size_t)p.lda * k + r;
           if (VEC) {
             if (r < p.R) v = ld4(ap);
           } else {
@@ -265,7 +288,7 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
         const int row = idx / (BK / 4), c4 = idx % (BK / 4);
         const int k = k0 + 4 * c4, r = r0 + row;
         if (idx < ROWS * (BK / 4) && r < p.R) {
-          const float* ap = p.A + (size_t)p.lda * r + k;
+          const float* ap = pA + (size_t)p.lda * r + k;
           if (VEC) {
             if (k < kend) v = ld4(ap);  // VEC implies K%4==0 and split boundaries %4==0
           } else {
@@ -282,9 +305,9 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       const int k = k0 + b_krow[it];
       if (b_ok[it] && k < kend) {
-        const int ch = k / p.TYX;
-        const int tap = k - ch * p.TYX;
-        const int a = tap / p.TX, b = tap - a * p.TX;
+        const int ch = k / pTYX;
+        const int tap = k - ch * pTYX;
+        const int a = tap / pTX, b = tap - a * pTX;
         const int ys = b_ys0[it] + p.dir * a, xs = b_xs0[it] + p.dir * b;
         if (ys >= 0 && ys < p.SH && xs >= 0 && xs < p.SW) {
           const float* sp = p.src + ((size_t)(ch * p.SH + ys) * p.SW + xs) * N + b_n[it];
@@ -301,7 +324,7 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
     }
   };
 
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf) __attribute__((always_inline)) {
     float* as = As + buf * A_STAGE;
     float* bs = Bs + buf * B_STAGE;
     if (!GLDS_A) {
@@ -339,9 +362,17 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
   }
   __syncthreads();
 
+  // With both tiles staged direct-to-LDS there is no register hand-over, so the next chunk's loads need not be
+  // issued as one block: slot i's address arithmetic (~25 VALU) + load goes between the MFMAs of k-step i, where
+  // it co-executes with the matrix pipe instead of delaying the chunk's first MFMA.
+  // Measured on conv4 (N=256): 126 TFLOP/s with the block fetch, 121 spread, 120 spread + sched_group_barrier
+  // interleave — the two resident waves of a SIMD already cover each other's staging phase, so SPREAD stays off.
+  constexpr bool SPREAD = false && GLDS_A && GLDS_B;
+  constexpr int NP = NA + NB, PPS = (NP + BK / 2 - 1) / (BK / 2);
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
-    if (c + 1 < nchunks) fetch(kbeg + (c + 1) * BK, buf ^ 1);
+    const bool more = c + 1 < nchunks;
+    if (!SPREAD && more) fetch(kbeg + (c + 1) * BK, buf ^ 1);
     const float* as = As + buf * A_STAGE;
     const float* bs = Bs + buf * B_STAGE + wc * BK * CW + NTC * li;
     if (!A_KCONTIG) {
@@ -352,22 +383,38 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
 #pragma unroll
       for (int t = 0; t < MT; ++t) a[0][t] = ar[lh * ROWS + t * 32];
       b4[0] = *reinterpret_cast<const fvec*>(bs + lh * CW);
-#pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
-        const int cur = kk & 1, nxt = cur ^ 1;
-        if (kk + 1 < BK / 2) {
+      static_for<0, BK / 2>([&](auto KK) __attribute__((always_inline)) {
+        constexpr int kk = decltype(KK)::value;
+        constexpr int cur = kk & 1, nxt = cur ^ 1;
+        if constexpr (kk + 1 < BK / 2) {
           const int krow = 2 * (kk + 1) + lh;
 #pragma unroll
           for (int t = 0; t < MT; ++t) a[nxt][t] = ar[krow * ROWS + t * 32];
           b4[nxt] = *reinterpret_cast<const fvec*>(bs + krow * CW);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (SPREAD && more) {
+          static_for<0, PPS>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int pi = kk * PPS + decltype(Q)::value;
+            if constexpr (pi < NA) fetch_a_piece(std::integral_constant<int, pi>{}, buf ^ 1);
+            else if constexpr (pi < NP) fetch_b_piece(std::integral_constant<int, pi - NA>{}, buf ^ 1);
+          });
+        }
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
           for (int u = 0; u < NTC; ++u)
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], b4[cur][u], acc[t][u], 0, 0, 0);
-      }
+        if (SPREAD) {
+          // issue order inside this k-step: one MFMA, then a few of the staging slot's VALU/SALU ops, repeated —
+          // the address arithmetic runs while the matrix pipe works instead of before or after the MFMA block
+#pragma unroll
+          for (int i = 0; i < MT * NTC; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);
+          }
+        }
+      });
     } else {
       const float* ar = as + (wr * MT * 32 + li) * APITCH + 4 * lh;
 #pragma unroll
@@ -392,10 +439,10 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
 
   // ---- epilogue ---------------------------------------------------------------------------------
   const int colid = col_tile * WC + wc;
-  if (colid >= p.ncols) return;
+  if (colid >= pncols) return;
   const int m = colid / p.nblk, blk = colid - m * p.nblk;
-  const int oy = m / p.GX, ox = m - oy * p.GX;
-  const int dpix = (oy * p.dsy + p.dy0) * p.DW + ox * p.dsx + p.dx0;
+  const int oy = m / pGX, ox = m - oy * pGX;
+  const int dpix = (oy * p.dsy + pdy0) * p.DW + ox * p.dsx + pdx0;
   const int n = blk * CW + NTC * li;
   if (n >= N) return;
   float* base = (p.splits > 1 ? p.partial + (size_t)split * p.slab : p.dst) + (size_t)dpix * N + n;
