@@ -24,7 +24,7 @@ class Edge:
     def ChooseEdgeClass(edge_config):
         # src/edge.cc:19-66
         table = {"FC": FCEdge, "CONVOLUTIONAL": ConvEdge, "MAXPOOL": MaxPoolEdge, "AVERAGE_POOL": AvgPoolEdge,
-                 "RESPONSE_NORM": ResponseNormEdge}
+                 "RESPONSE_NORM": ResponseNormEdge, "CONV_ONETOONE": ConvOneToOneEdge}
         if edge_config.edge_type not in table:
             raise SystemExit(f"Error: Undefined edge type {edge_config.edge_type} (out of hot-path scope).")
         return table[edge_config.edge_type](edge_config)
@@ -500,6 +500,61 @@ class FCEdge(EdgeWithWeight):
         if not self.has_no_bias_:
             db = self.tied_edge_.GetGradBias() if self.is_tied_ else self.grad_bias_
             deriv_output.SumRows(db, scale_targets, self.scale_gradients_ / batch_size)
+        self.IncrementNumGradsReceived()
+
+
+class ConvOneToOneEdge(FCEdge):
+    """src/conv_onetoone_edge.{h,cc}: a 1x1 convolution (network-in-network layer) = the FC GEMMs on the
+    (N*X*Y, C) view of the same CHWN bytes, so pixel and image together form the contiguous "image" axis of the
+    gather-GEMM kernels.  Everything but the reshapes is FCEdge's."""
+
+    def SetImageSize(self, y, x, t):
+        # src/conv_onetoone_edge.cc:8-13
+        Edge.SetImageSize(self, y, x, t)
+        self.num_modules_y_, self.num_modules_x_, self.num_modules_t_ = y, x, t
+
+    def _input_size(self):
+        return self.num_input_channels_
+
+    def GetDescription(self):
+        return (f"{self.name_}  One-to-One Convolutional Kernel: {self.num_input_channels_} : {self.num_output_channels_} Layer: "
+                f"{self.image_size_y_}-{self.image_size_x_}-{self.num_input_channels_} : {self.num_modules_y_}-{self.num_modules_x_}-"
+                f"{self.num_output_channels_}")
+
+    class _Flat:
+        """with-block: view activations as (N*X*Y, channels) and restore (batch, -1) on exit (:58-59,72-73)."""
+
+        def __init__(self, *pairs):
+            self.pairs = [(m, ch) for m, ch in pairs if m is not None]
+
+        def __enter__(self):
+            self.rows = [m.GetRows() for m, _ in self.pairs]
+            for m, ch in self.pairs:
+                m.Reshape(-1, ch)
+
+        def __exit__(self, *exc):
+            for (m, _), rows in zip(self.pairs, self.rows):
+                m.Reshape(rows, -1)
+
+    def ComputeUp(self, input, output, overwrite, train=True, fuse_relu=None):
+        with self._Flat((input, self.num_input_channels_), (output, self.num_output_channels_)):
+            FCEdge.ComputeUp(self, input, output, overwrite, train, fuse_relu)
+
+    def ComputeDown(self, deriv_output, input, output, deriv_input, overwrite, fuse_mask=None):
+        with self._Flat((deriv_output, self.num_output_channels_), (deriv_input, self.num_input_channels_),
+                        (input if fuse_mask is not None else None, self.num_input_channels_)):
+            FCEdge.ComputeDown(self, deriv_output, input, output, deriv_input, overwrite, fuse_mask)
+
+    def ComputeOuter(self, input, deriv_output):
+        # scale_gradients / batch_size uses the layer's batch (rows before the reshape), :92-104
+        batch_size = input.GetRows()
+        dw = self.tied_edge_.GetGradWeight() if self.is_tied_ else self.grad_weights_
+        scale_targets = 1 if self.GetNumGradsReceived() > 0 else 0
+        with self._Flat((input, self.num_input_channels_), (deriv_output, self.num_output_channels_)):
+            Matrix.Dot(deriv_output, input, dw, scale_targets, self.scale_gradients_ / batch_size, True, False)
+            if not self.has_no_bias_:
+                db = self.tied_edge_.GetGradBias() if self.is_tied_ else self.grad_bias_
+                deriv_output.SumRows(db, scale_targets, self.scale_gradients_ / batch_size)
         self.IncrementNumGradsReceived()
 
 

@@ -50,6 +50,12 @@ def _fc(src, dst, eps=0.01, mom=0.9, tau=2000, l2=0.0005, init_wt=1.0, init_bias
             f"  init_wt: {init_wt}\n  init_bias: {init_bias}\n" + _OPT_W.format(eps=eps, mom=mom, tau=tau, l2=l2, extra=extra) + grad_check + "}\n\n")
 
 
+def _nin(src, dst, eps=0.01, mom=0.9, tau=2000, init_wt=1.0, grad_check=""):
+    """CONV_ONETOONE (1x1 conv) with the unit-norm row constraint the reference's NIN model uses."""
+    return (f'edge {{\n  source: "{src}"\n  dest: "{dst}"\n  edge_type: CONV_ONETOONE\n  initialization: DENSE_UNIFORM_SQRT_FAN_IN\n'
+            f"  init_wt: {init_wt}\n" + _OPT_W.format(eps=eps, mom=mom, tau=tau, l2=0.0, extra="\n    weight_norm_constraint: 1") + grad_check + "}\n\n")
+
+
 def _pool(src, dst, k, stride, pad=0, kind="MAXPOOL"):
     return (f'edge {{\n  source: "{src}"\n  dest: "{dst}"\n  edge_type: {kind}\n  kernel_size: {k}\n  stride : {stride}\n'
             f"  padding: {pad}\n}}\n\n")
@@ -93,6 +99,36 @@ def alexnet(image_size=224, num_classes=1000, dropprob=0.4, grad_check=False):
     s += _pool("hidden5_conv", "hidden5_maxpool", 3, 2, 1)
     s += _fc("hidden5_maxpool", "hidden6", norm_limit=4, grad_check=gc) + _fc("hidden6", "hidden7", norm_limit=4, grad_check=gc)
     s += _fc("hidden7", "output", norm_limit=4, grad_check=gc)
+    return s
+
+
+def alexnet_nin(image_size=224, num_classes=1000, grad_check=False, dropout=True):
+    """examples/imagenet/CLS_net_20140801232522.pbtxt: the network-in-network variant — 1x1
+    CONV_ONETOONE layers after conv2..conv5, 512-channel conv5, dropout 0.1/0.3/0.5."""
+    gc = _gc(grad_check)
+    R = "RECTIFIED_LINEAR"
+    d = (lambda p: p) if dropout else (lambda p: 0.0)
+    s = _header("CLS_net", seed=80638)
+    s += _layer("input", 3, size=image_size)
+    s += _layer("hidden1_conv", 96, R) + _layer("hidden1_maxpool", 96) + _layer("hidden1_rnorm", 96, R)
+    s += _layer("hidden2_conv", 256, R) + _layer("hidden2_conv_nin1", 256, R) + _layer("hidden2_maxpool", 256) + _layer("hidden2_rnorm", 256, R)
+    s += _layer("hidden3_conv", 384, R) + _layer("hidden3_conv_nin1", 768, R)
+    s += _layer("hidden4_conv", 384, R) + _layer("hidden4_conv_nin1", 768, R, d(0.1)) + _layer("hidden4_conv_nin2", 384, R)
+    s += _layer("hidden5_conv", 512, R) + _layer("hidden5_conv_nin1", 1024, R, d(0.3)) + _layer("hidden5_conv_nin2", 512, R)
+    s += _layer("hidden5_maxpool", 512)
+    s += _layer("hidden6", 4096, R, d(0.5)) + _layer("hidden7", 4096, R, d(0.5)) + _layer("output", num_classes, "SOFTMAX")
+    s += _conv("input", "hidden1_conv", 7, 2, 1, l2=0.0, grad_check=gc)
+    s += _pool("hidden1_conv", "hidden1_maxpool", 3, 2, 1) + _rnorm("hidden1_maxpool", "hidden1_rnorm")
+    s += _conv("hidden1_rnorm", "hidden2_conv", 5, 2, 1, l2=0.0, init_bias=1.0, grad_check=gc) + _nin("hidden2_conv", "hidden2_conv_nin1", grad_check=gc)
+    s += _pool("hidden2_conv_nin1", "hidden2_maxpool", 3, 2, 1) + _rnorm("hidden2_maxpool", "hidden2_rnorm")
+    s += _conv("hidden2_rnorm", "hidden3_conv", 3, 1, 1, grad_check=gc) + _nin("hidden3_conv", "hidden3_conv_nin1", grad_check=gc)
+    s += _conv("hidden3_conv_nin1", "hidden4_conv", 3, 1, 1, init_bias=1.0, grad_check=gc)
+    s += _nin("hidden4_conv", "hidden4_conv_nin1", grad_check=gc) + _nin("hidden4_conv_nin1", "hidden4_conv_nin2", grad_check=gc)
+    s += _conv("hidden4_conv_nin2", "hidden5_conv", 3, 1, 0, init_bias=1.0, grad_check=gc)
+    s += _nin("hidden5_conv", "hidden5_conv_nin1", grad_check=gc) + _nin("hidden5_conv_nin1", "hidden5_conv_nin2", grad_check=gc)
+    s += _pool("hidden5_conv_nin2", "hidden5_maxpool", 3, 2, 1)
+    s += _fc("hidden5_maxpool", "hidden6", norm_limit=4, grad_check=gc) + _fc("hidden6", "hidden7", norm_limit=4, grad_check=gc)
+    s += _fc("hidden7", "output", init_wt=0.1, norm_limit=4, grad_check=gc)
     return s
 
 

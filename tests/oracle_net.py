@@ -15,8 +15,11 @@ def _geom(e, src, N, pool=False):
                 -d.padding_y, -d.padding_x)
 
 
-def forward_backward(net, x, labels, impl=None):
-    from convnet_amd.edge import AvgPoolEdge, ConvEdge, FCEdge, MaxPoolEdge, ResponseNormEdge
+def forward_backward(net, x, labels, impl=None, force=None):
+    """``force`` = (states, derivs) dicts of flat arrays taken from the device run: the BACKWARD ops are then each fed
+    the device's own inputs (teacher forcing), so one ReLU unit or pool window that gates differently within fp32
+    rounding cannot colour everything upstream of it — every op is still checked on realistic whole-net data."""
+    from convnet_amd.edge import AvgPoolEdge, ConvEdge, ConvOneToOneEdge, FCEdge, MaxPoolEdge, ResponseNormEdge
     O = impl or oracle.port
     N = labels.size
     acts = {net.input_layers_[0].GetName(): np.ascontiguousarray(x.reshape(-1))}
@@ -42,7 +45,9 @@ def forward_backward(net, x, labels, impl=None):
             y = O.rnorm(a.reshape(C, -1, 1, N), e.num_filters_response_norm_, e.add_scale_, e.pow_scale_, e.blocked_).reshape(-1)
         elif isinstance(e, FCEdge):
             Fo = l.GetNumChannels()
-            y = O.dot(np.ascontiguousarray(a.reshape(-1, N)), e.GetWeight().ToNumpy(), np.zeros((Fo, N), np.float32), 0.0, 1.0, False, True)
+            # CONV_ONETOONE = the same GEMM on the (N*X*Y, C) view: pixel and image together are the "case" axis
+            Nv = a.size // src.GetNumChannels() if isinstance(e, ConvOneToOneEdge) else N
+            y = O.dot(np.ascontiguousarray(a.reshape(-1, Nv)), e.GetWeight().ToNumpy(), np.zeros((Fo, Nv), np.float32), 0.0, 1.0, False, True)
             y = O.add_row_vec(y, e.GetBias().ToNumpy().reshape(-1)).reshape(-1)
         else:
             raise NotImplementedError(type(e))
@@ -52,14 +57,15 @@ def forward_backward(net, x, labels, impl=None):
             y = O.softmax_row_major(y.reshape(l.GetNumChannels(), N)).reshape(-1)
         acts[l.GetName()] = y
     out = net.output_layers_[0]
-    derivs = {out.GetName(): O.softmax_grad_row_major(acts[out.GetName()].reshape(out.GetNumChannels(), N), labels).reshape(-1)}
+    f_acts, f_derivs = force if force is not None else (acts, None)
+    derivs = {out.GetName(): O.softmax_grad_row_major(f_acts[out.GetName()].reshape(out.GetNumChannels(), N), labels).reshape(-1)}
     grads = {}
     for l in reversed(net.layers_):
         if l.IsOutput():
             continue
         e = l.outgoing_edge_[0]
         dst = e.GetDest()
-        a, dy, yact = acts[l.GetName()], derivs[dst.GetName()], acts[dst.GetName()]
+        a, dy, yact = f_acts[l.GetName()], (f_derivs or derivs)[dst.GetName()], f_acts[dst.GetName()]
         dx = None
         if isinstance(e, ConvEdge):
             g = _geom(e, l, N)
@@ -69,13 +75,14 @@ def forward_backward(net, x, labels, impl=None):
             if not l.IsInput():
                 dx = O.conv_down(g, dy.reshape(g.out_shape()), e.GetWeight().ToNumpy().reshape(g.filt_shape())).reshape(-1)
         elif isinstance(e, FCEdge):
-            D, Fo = a.size // N, dst.GetNumChannels()
-            a2, dy2 = np.ascontiguousarray(a.reshape(D, N)), np.ascontiguousarray(dy.reshape(Fo, N))
+            Nv = a.size // l.GetNumChannels() if isinstance(e, ConvOneToOneEdge) else N
+            D, Fo = a.size // Nv, dst.GetNumChannels()
+            a2, dy2 = np.ascontiguousarray(a.reshape(D, Nv)), np.ascontiguousarray(dy.reshape(Fo, Nv))
             dw = O.dot(dy2, a2, np.zeros((D, Fo), np.float32), 0.0, e.scale_gradients_ / N, True, False)
             db = O.sum_by_axis(dy2, np.zeros(Fo, np.float32), 0, e.scale_gradients_ / N, 0.0)
             grads[e.GetName()] = (dw.reshape(-1), db)
             if not l.IsInput():
-                dx = O.dot(dy2, e.GetWeight().ToNumpy(), np.zeros((D, N), np.float32), 0.0, 1.0).reshape(-1)
+                dx = O.dot(dy2, e.GetWeight().ToNumpy(), np.zeros((D, Nv), np.float32), 0.0, 1.0).reshape(-1)
         elif isinstance(e, MaxPoolEdge):
             g = _geom(e, l, N, True)
             dx = O.max_pool_undo(g, a.reshape(g.in_shape()), dy.reshape(g.pooled_shape()), yact.reshape(g.pooled_shape())).reshape(-1)

@@ -35,7 +35,8 @@ def test_pbtxt_reader_defaults_presence_and_errors():
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted")
-@pytest.mark.parametrize("gen,path", [(models.alexnet, "imagenet/CLS_net_20140621074703.pbtxt"), (models.mnist_conv, "mnist-conv/net.pbtxt")])
+@pytest.mark.parametrize("gen,path", [(models.alexnet, "imagenet/CLS_net_20140621074703.pbtxt"), (models.mnist_conv, "mnist-conv/net.pbtxt"),
+                                      (models.alexnet_nin, "imagenet/CLS_net_20140801232522.pbtxt")])
 def test_generated_models_equal_reference_pbtxt(gen, path):
     ref, mine = pbtxt.read(os.path.join(REF, path)), pbtxt.parse(gen())
 
@@ -44,7 +45,7 @@ def test_generated_models_equal_reference_pbtxt(gen, path):
         for e in m.edge:
             w, b = e.weight_optimizer, e.bias_optimizer
             out.append((e.source, e.dest, e.edge_type, e.kernel_size, e.stride, e.padding, e.shared_bias, e.initialization, e.init_wt,
-                        e.init_bias, w.epsilon, w.final_momentum, w.momentum_transition_timescale, w.l2_decay, w.weight_norm_limit,
+                        e.init_bias, w.epsilon, w.final_momentum, w.momentum_transition_timescale, w.l2_decay, w.weight_norm_limit, w.weight_norm_constraint,
                         b.epsilon, b.final_momentum, b.l2_decay, e.add_scale, e.pow_scale, e.frac_of_filters_response_norm))
         return out
     assert sig(ref) == sig(mine)

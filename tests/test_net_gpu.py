@@ -104,14 +104,23 @@ def test_fprop_activations_match_cpu_oracle_layer_by_layer(gpu):
         assert rel_err(got, y) < TOL, (l.GetName(), rel_err(got, y))
 
 
-@pytest.mark.parametrize("which,fused", [("tiny_alex", False), ("tiny_alex", True), ("lenet5", False), ("mnist_conv", True)])
+def nets(which):
+    from convnet_amd import models
+    if which == "tiny_alex":
+        return small_alexnet()
+    if which == "nin67":   # the reference's second ImageNet model (CONV_ONETOONE layers) at 67x67, 10 classes, no dropout
+        return models.alexnet_nin(image_size=67, num_classes=10, dropout=False)
+    return {"mnist_conv": models.mnist_conv, "lenet5": models.lenet5}[which]()
+
+
+@pytest.mark.parametrize("which,fused", [("tiny_alex", False), ("tiny_alex", True), ("lenet5", False), ("mnist_conv", True),
+                                         ("nin67", False), ("nin67", True)])
 def test_bprop_gradients_match_cpu_oracle_whole_net(gpu, which, fused):
     """Analytic-vs-analytic: every layer derivative and every weight/bias gradient of one
     Fprop/ComputeDeriv/Bprop equals the CPU oracle's (conv dgrad+wgrad, pool undo with ties,
-    response-norm undo, FC, shared-bias gradients), fused and unfused."""
-    from convnet_amd import models
+    response-norm undo, FC, 1x1 conv, shared-bias gradients), fused and unfused."""
     from oracle_net import forward_backward
-    text = {"tiny_alex": small_alexnet(), "mnist_conv": models.mnist_conv(), "lenet5": models.lenet5()}[which]
+    text = nets(which)
     N = 8
     net = build(text, N, fused=fused)
     for l in net.layers_:
@@ -122,7 +131,15 @@ def test_bprop_gradients_match_cpu_oracle_whole_net(gpu, which, fused):
     net.Fprop(True)
     net.ComputeDeriv()
     net.Bprop()
-    acts, derivs, grads = forward_backward(net, x, labels)
+    # The deep NIN net (~190k ReLU units per image behind reductions up to 6912 terms) always has a few units whose
+    # pre-activation is within fp32 rounding of 0 and gate differently on GPU and CPU; each flip colours everything
+    # upstream of it (seen: 1 unit of 98,304 -> 10 % of one image's conv1 derivative).  For that net the backward ops are
+    # teacher-forced: every op gets the device's own states / incoming derivatives and must reproduce the device's output.
+    force = None
+    if which == "nin67":
+        force = ({l.GetName(): l.GetState().ToNumpy().reshape(-1) for l in net.layers_},
+                 {l.GetName(): l.GetDeriv().ToNumpy().reshape(-1) for l in net.layers_ if not l.IsInput()})
+    acts, derivs, grads = forward_backward(net, x, labels, force=force)
     for l in net.layers_:
         assert rel_err(l.GetState().ToNumpy().reshape(-1), acts[l.GetName()]) < TOL, ("state", l.GetName())
         if l.GetName() in derivs and not l.IsInput():
@@ -134,10 +151,9 @@ def test_bprop_gradients_match_cpu_oracle_whole_net(gpu, which, fused):
             assert rel_err(e.GetGradBias().ToNumpy().reshape(-1), db) < TOL, ("db", e.GetName())
 
 
-@pytest.mark.parametrize("which", ["tiny_alex", "mnist_conv", "lenet5"])
+@pytest.mark.parametrize("which", ["tiny_alex", "mnist_conv", "lenet5", "nin67"])
 def test_fused_equals_unfused_forward_backward_and_update(gpu, which):
-    from convnet_amd import models
-    text = {"tiny_alex": small_alexnet(), "mnist_conv": models.mnist_conv(), "lenet5": models.lenet5()}[which]
+    text = nets(which)
     N = 32
     a, b = build(text, N, fused=False), build(text, N, fused=True)
     copy_params(a, b)
