@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
-    ap.add_argument("--model", default="alexnet", choices=["alexnet", "mnist_conv", "lenet5", "vgg"])
+    ap.add_argument("--model", default="alexnet", choices=["alexnet", "alexnet_nin", "mnist_conv", "lenet5", "vgg"])
     ap.add_argument("--side-stream-update", action="store_true",
                     help="enqueue each edge's optimizer step on a second stream during Bprop (measured: no gain on 1 GPU)")
     ap.add_argument("--timer-every", type=int, default=4, help="steps between kernel-timer (HIP event) sampled steps")
