@@ -115,6 +115,7 @@ def main():
                     help="enqueue each edge's optimizer step on a second stream during Bprop (measured: no gain on 1 GPU)")
     ap.add_argument("--timer-every", type=int, default=4, help="steps between kernel-timer (HIP event) sampled steps")
     ap.add_argument("--no-kernel-timers", action="store_true", help="diagnostic: no per-launch HIP events (roofline fields empty)")
+    ap.add_argument("--staged-input", action="store_true", help="GPU-resident 256x256 chunk + crop/flip/transpose staging per batch instead of pre-staged batches")
     ap.add_argument("--unfused", action="store_true", help="issue the reference's unfused Matrix-call sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
@@ -154,7 +155,20 @@ def main():
     net = ConvNet(text, fused=not args.unfused, process_id=rank, num_processes=world, exchange=exchange,
                   overlap_update=args.side_stream_update)
     net.SetBatchsize(args.batch)
-    data = SyntheticDataHandler(net, args.batch, seed=1000 + rank, num_batches=2)
+    if args.staged_input:
+        # the reference's real input path: a GPU-resident chunk of 256x256 images, per-batch random 224 crop + flip +
+        # transpose to CHWN by extract_patches, mean/std normalised at load, columns shuffled at chunk wrap
+        import numpy as np
+        from convnet_amd.datahandler import ChunkDataHandler
+        inp = [l for l in net.layers_ if l.IsInput()][0]
+        crop, colors = inp.GetSizeY(), inp.GetNumChannels()
+        rng = np.random.default_rng(1000 + rank)
+        chunk = 3 * args.batch
+        data = ChunkDataHandler(rng.integers(0, 256, (chunk, colors * (crop + 32) ** 2), dtype=np.uint8),
+                                rng.integers(0, net.layers_[-1].GetNumChannels(), chunk), args.batch, crop + 32, crop, colors,
+                                mean=np.float32(120.0), std=np.float32(60.0), seed=rank)
+    else:
+        data = SyntheticDataHandler(net, args.batch, seed=1000 + rank, num_batches=2)
     net.SetupDataset(data)
     net.AllocateMemory(False)
     fwd_macs, train_macs = models.count_macs(net)
@@ -226,7 +240,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.model} (convnet_amd.models.{args.model}" + (": the reference's AlexNet-class ILSVRC pbtxt) " if args.model == "alexnet" else ") ") +
-                                   f"training step, 224x224x3 synthetic N(0,1) images, {args.batch} images per GPU, "
+                                   f"training step, 224x224x3 synthetic " + ("uint8-valued 256x256 chunk, random crop+flip staged on the GPU each step, " if args.staged_input else "N(0,1) images, ") + f"{args.batch} images per GPU, "
                                    f"SGD+momentum+L2, dropout on, {'fused' if not args.unfused else 'unfused'} ABI calls",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" + ("" if world == 1 else (" rccl-allreduce " + ("overlapped" if not args.no_overlap else "serial"))),

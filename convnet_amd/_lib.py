@@ -106,6 +106,13 @@ def _load():
     sig("init_empty", I, M, I, I)
     sig("write_at", I, M, I, I, F)
     sig("read_from", F, M, I, I, P(I))
+    sig("extract_patches", I, M, M, M, M, M, I, I, I, I)
+    sig("shuffleColumns", I, M, M)
+    for n in ("add_col_vec", "div_by_col_vec", "mult_by_row_vec", "div_by_row_vec"):
+        sig(n, I, M, M, M)
+    sig("add_col_mult", I, M, M, M, F)
+    sig("add_to_each_pixel", I, M, M, M, F)
+    sig("normalize_by_axis", I, M, M, I)
     for n in ("convUpGemm", "convDownGemm", "convUp", "convDown"):
         sig(n, None, M, M, M, S, S, S, ConvDesc, F)
     sig("convOutpGemm", None, M, M, M, S, S, S, ConvDesc, F, F)

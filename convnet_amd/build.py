@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libconvnet_hip.so")
-SOURCES = ["state.hip", "gather_gemm.hip", "pool_norm.hip", "elementwise.hip"]
+SOURCES = ["state.hip", "gather_gemm.hip", "pool_norm.hip", "elementwise.hip", "input_staging.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
 
 

@@ -246,6 +246,35 @@ class Matrix:
         else:
             _chk(lib.add_row_mult(self.GetMat(), v.GetMat(), self.GetMat(), float(alpha)), "add_row_mult")
 
+    # ---- input staging (src/matrix.cc: AddColVec, DivideByColVec, MultByRowVec, NormalizeColumnwise, ShuffleColumns,
+    #      AddToEachPixel, ExtractPatches, CopyTranspose — the DataHandler's GPU-side calls) ------------------------
+    def AddColVec(self, v, alpha=1.0):
+        _chk(lib.add_col_mult(self.GetMat(), v.GetMat(), self.GetMat(), float(alpha)), "add_col_mult")
+
+    def DivideByColVec(self, v):
+        _chk(lib.div_by_col_vec(self.GetMat(), v.GetMat(), self.GetMat()), "div_by_col_vec")
+
+    def MultByRowVec(self, v):
+        _chk(lib.mult_by_row_vec(self.GetMat(), v.GetMat(), self.GetMat()), "mult_by_row_vec")
+
+    def DivideByRowVec(self, v):
+        _chk(lib.div_by_row_vec(self.GetMat(), v.GetMat(), self.GetMat()), "div_by_row_vec")
+
+    def NormalizeColumnwise(self):
+        _chk(lib.normalize_by_axis(self.GetMat(), self.GetMat(), 0), "normalize_by_axis")
+
+    def ShuffleColumns(self, rand_perm_indices):
+        _chk(lib.shuffleColumns(self.GetMat(), rand_perm_indices.GetMat()), "shuffleColumns")
+
+    def AddToEachPixel(self, v, mult):
+        _chk(lib.add_to_each_pixel(self.GetMat(), v.GetMat(), self.GetMat(), float(mult)), "add_to_each_pixel")
+
+    @staticmethod
+    def ExtractPatches(source, dest, width_offset, height_offset, flip_bit, image_size_y, image_size_x, patch_size_y, patch_size_x):
+        # argument order of src/matrix.cc / CPUMatrix.cc:920-933: (y, x) sizes in, (x, y) passed to the kernel
+        _chk(lib.extract_patches(source.GetMat(), dest.GetMat(), width_offset.GetMat(), height_offset.GetMat(), flip_bit.GetMat(),
+                                 int(image_size_x), int(image_size_y), int(patch_size_x), int(patch_size_y)), "Error extracting patches")
+
     def Mult(self, val):
         if isinstance(val, Matrix):
             _chk(lib.mult_elementwise(self.GetMat(), val.GetMat(), self.GetMat(), 0.0), "mult")

@@ -114,6 +114,22 @@ int init_empty(cudamat* mat, int m, int n);
 int write_at(cudamat* mat, int row, int col, float val);
 float read_from(cudamat* mat, int row, int col, int* err_code);
 
+/* ---- GPU-side input staging: the DataHandler step right before the hot path (datahandler.cc:146-198,496-532) --------
+ * The dataset chunk lives on the GPU as (dims, cases): one case per COLUMN, [colour][row][col] contiguous. */
+/* random crop + horizontal flip + transpose into the (cases, colours*ph*pw) CHWN batch (cudamat.cuh:265, cudamat.cu:2699);
+ * width_offset / height_offset / flip hold one float per case (flip > 0.5 mirrors the source column). */
+int extract_patches(cudamat* images, cudamat* patches, cudamat* width_offset, cudamat* height_offset, cudamat* flip,
+                    int img_width, int img_height, int patch_width, int patch_height);
+/* in place: for every column pair (2j, 2j+1) swap columns idx[2j] and idx[2j+1] (cudamat.cu:2655, kShuffleColumns) */
+int shuffleColumns(cudamat* source, cudamat* rand_perm_indices);
+int add_col_vec(cudamat* mat, cudamat* vec, cudamat* target);                 /* cudamat.cuh:165 */
+int add_col_mult(cudamat* mat, cudamat* vec, cudamat* target, float mult);    /* mean subtraction: mult = -1 */
+int div_by_col_vec(cudamat* mat, cudamat* vec, cudamat* target);              /* cudamat.cuh:176: divide by std */
+int mult_by_row_vec(cudamat* mat, cudamat* vec, cudamat* target);
+int div_by_row_vec(cudamat* mat, cudamat* vec, cudamat* target);
+int add_to_each_pixel(cudamat* mat1, cudamat* mat2, cudamat* target, float mult);   /* PCA colour noise */
+int normalize_by_axis(cudamat* mat, cudamat* target, int axis);               /* axis 0: subtract each column's mean */
+
 /* ---- convolution: cudamat/cudamat_conv_gemm.cuh:36-49 ----------------------------------------------
  * targets = scaleTargets*targets + conv(...).  scaleTargets is the reference's 0/1 accumulate flag but
  * any value is honoured.  Implemented as implicit-GEMM on fp32 MFMA (no im2col buffer). */

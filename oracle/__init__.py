@@ -225,6 +225,49 @@ class _Port:
         self.lib.oracle_dropout(_p(mat), _p(uniform), ctypes.c_size_t(mat.size), ctypes.c_float(dropprob), ctypes.c_float(val), ctypes.c_float(scale))
         return mat
 
+    # ---- input staging: matrices are numpy arrays of shape (cols, rows) holding the column-major bytes -------------
+    def extract_patches(self, images, wo, ho, flip, img_w, img_h, pw, ph):
+        """images (num_images, dims) -> CHWN batch (colors, ph, pw, num_images)."""
+        n, dims = images.shape
+        colors = dims // (img_w * img_h)
+        out = np.zeros((colors, ph, pw, n), np.float32)
+        self._extract(images, n, dims, colors, out, wo, ho, flip, img_w, img_h, pw, ph)
+        return out
+
+    def _extract(self, images, n, dims, colors, out, wo, ho, flip, img_w, img_h, pw, ph):
+        ci = ctypes.c_int
+        self.lib.oracle_extract_patches(_p(images), ci(n), ci(colors), _p(out), _p(wo), _p(ho), _p(flip), ci(img_w), ci(img_h), ci(pw), ci(ph))
+
+    def shuffle_columns(self, mat, perm):
+        self.lib.oracle_shuffle_columns(_p(mat), ctypes.c_int(mat.shape[1]), ctypes.c_int(mat.shape[0]), _p(perm))
+        return mat
+
+    def add_col_mult(self, mat, vec, mult):
+        self.lib.oracle_add_col_mult(_p(mat), ctypes.c_int(mat.shape[1]), ctypes.c_int(mat.shape[0]), _p(vec), ctypes.c_float(mult))
+        return mat
+
+    def div_by_col_vec(self, mat, vec):
+        self.lib.oracle_div_by_col_vec(_p(mat), ctypes.c_int(mat.shape[1]), ctypes.c_int(mat.shape[0]), _p(vec))
+        return mat
+
+    def mult_by_row_vec(self, mat, vec):
+        self.lib.oracle_mult_by_row_vec(_p(mat), ctypes.c_int(mat.shape[1]), ctypes.c_int(mat.shape[0]), _p(vec))
+        return mat
+
+    def normalize_columns(self, mat):
+        self.lib.oracle_normalize_columns(_p(mat), ctypes.c_int(mat.shape[1]), ctypes.c_int(mat.shape[0]))
+        return mat
+
+    def add_to_each_pixel(self, mat1, mat2, mult):
+        self.lib.oracle_add_to_each_pixel(_p(mat1), ctypes.c_int(mat1.shape[1]), ctypes.c_int(mat1.shape[0]), _p(mat2),
+                                          ctypes.c_int(mat2.shape[0]), ctypes.c_float(mult))
+        return mat1
+
+    def copy_transpose(self, src):
+        dst = np.zeros((src.shape[1], src.shape[0]), np.float32)
+        self.lib.oracle_copy_transpose(_p(src), ctypes.c_int(src.shape[1]), ctypes.c_int(src.shape[0]), _p(dst))
+        return dst
+
 
 class _Ref(_Port):
     """Same numpy API, executed by the reference's own compiled code."""
@@ -339,6 +382,40 @@ class _Ref(_Port):
     def normlimit_rows(self, mat, norm, constraint):
         self.lib.ref_normlimit_by_axis(_p(mat), ctypes.c_int(mat.shape[1]), ctypes.c_int(mat.shape[0]), ctypes.c_int(1), ctypes.c_float(norm), ctypes.c_int(int(constraint)))
         return mat
+
+    def _extract(self, images, n, dims, colors, out, wo, ho, flip, img_w, img_h, pw, ph):
+        ci = ctypes.c_int
+        assert self.lib.ref_extract_patches(_p(images), ci(dims), ci(n), _p(out), _p(wo), _p(ho), _p(flip), ci(img_w), ci(img_h), ci(pw), ci(ph)) == 0
+
+    def shuffle_columns(self, mat, perm):
+        assert self.lib.ref_shuffle_columns(_p(mat), ctypes.c_int(mat.shape[1]), ctypes.c_int(mat.shape[0]), _p(perm)) == 0
+        return mat
+
+    def add_col_mult(self, mat, vec, mult):
+        assert self.lib.ref_add_col_mult(_p(mat), ctypes.c_int(mat.shape[1]), ctypes.c_int(mat.shape[0]), _p(vec), ctypes.c_float(mult)) == 0
+        return mat
+
+    def div_by_col_vec(self, mat, vec):
+        assert self.lib.ref_div_by_col_vec(_p(mat), ctypes.c_int(mat.shape[1]), ctypes.c_int(mat.shape[0]), _p(vec)) == 0
+        return mat
+
+    def mult_by_row_vec(self, mat, vec):
+        assert self.lib.ref_mult_by_row_vec(_p(mat), ctypes.c_int(mat.shape[1]), ctypes.c_int(mat.shape[0]), _p(vec)) == 0
+        return mat
+
+    def normalize_columns(self, mat):
+        assert self.lib.ref_normalize_columns(_p(mat), ctypes.c_int(mat.shape[1]), ctypes.c_int(mat.shape[0])) == 0
+        return mat
+
+    def add_to_each_pixel(self, mat1, mat2, mult):
+        assert self.lib.ref_add_to_each_pixel(_p(mat1), ctypes.c_int(mat1.shape[1]), ctypes.c_int(mat1.shape[0]), _p(mat2),
+                                              ctypes.c_int(mat2.shape[0]), ctypes.c_float(mult)) == 0
+        return mat1
+
+    def copy_transpose(self, src):
+        dst = np.zeros((src.shape[1], src.shape[0]), np.float32)
+        assert self.lib.ref_copy_transpose(_p(src), ctypes.c_int(src.shape[1]), ctypes.c_int(src.shape[0]), _p(dst)) == 0
+        return dst
 
     def sgd_step(self, grad, param, history, l2_decay, gradient_clip, epsilon, momentum, norm_limit=0.0, norm_constraint=0.0):
         self.lib.ref_sgd_step(_p(grad), _p(param), _p(history), ctypes.c_int(param.shape[1]), ctypes.c_int(param.shape[0]),

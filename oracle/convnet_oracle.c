@@ -452,4 +452,68 @@ void oracle_dropout(float* mat, const float* uniform, size_t len, float dropprob
   }
 }
 
-int oracle_version(void) { return 1; }
+/* ---- input staging (the DataHandler's GPU-side calls) ------------------------------------------------------------
+ * images (dims, num_images): one case per column, [colour][row][col] contiguous; patches = CHWN batch.
+ * eigenmat.cc:2046-2090 (extract_patches), :1962-1988 (shuffleColumns), :325-344, :519-535, :499-517, :970-997, :346-366. */
+void oracle_extract_patches(const float* images, int num_images, int colors, float* patches, const float* wo, const float* ho,
+                            const float* flip, int img_w, int img_h, int pw, int ph) {
+  for (int n = 0; n < num_images; ++n)
+    for (int dc = 0; dc < pw; ++dc) {
+      int sc = (int)wo[n] + dc;
+      if (flip[n] > 0.5f) sc = img_w - sc - 1;
+      for (int dr = 0; dr < ph; ++dr) {
+        const int sr = (int)ho[n] + dr;
+        for (int c = 0; c < colors; ++c)
+          patches[(size_t)n + (size_t)num_images * (dc + (size_t)pw * (dr + (size_t)ph * c))] =
+              images[(size_t)sc + (size_t)img_w * (sr + (size_t)img_h * (c + (size_t)colors * n))];
+      }
+    }
+}
+
+void oracle_shuffle_columns(float* mat, int height, int width, const float* perm) {
+  for (int c = 0; c + 1 < width; c += 2) {
+    float* a = mat + (size_t)height * (int)perm[c];
+    float* b = mat + (size_t)height * (int)perm[c + 1];
+    for (int i = 0; i < height; ++i) { const float t = a[i]; a[i] = b[i]; b[i] = t; }
+  }
+}
+
+void oracle_add_col_mult(float* mat, int h, int w, const float* vec, float mult) {
+  for (int j = 0; j < w; ++j)
+    for (int i = 0; i < h; ++i) { volatile float t = vec[i] * mult; mat[(size_t)i + (size_t)h * j] += t; }
+}
+
+void oracle_div_by_col_vec(float* mat, int h, int w, const float* vec) {
+  for (int j = 0; j < w; ++j)
+    for (int i = 0; i < h; ++i) mat[(size_t)i + (size_t)h * j] /= vec[i];
+}
+
+void oracle_mult_by_row_vec(float* mat, int h, int w, const float* vec) {
+  for (int j = 0; j < w; ++j)
+    for (int i = 0; i < h; ++i) mat[(size_t)i + (size_t)h * j] *= vec[j];
+}
+
+void oracle_normalize_columns(float* mat, int h, int w) {
+  for (int j = 0; j < w; ++j) {
+    float* col = mat + (size_t)h * j;
+    float s = 0.f;
+    for (int i = 0; i < h; ++i) s += col[i];
+    s /= h;
+    for (int i = 0; i < h; ++i) col[i] -= s;
+  }
+}
+
+void oracle_add_to_each_pixel(float* mat1, int height, int width, const float* mat2, int colors, float mult) {
+  const size_t num_pix = (size_t)height * width / colors;
+  for (size_t i = 0; i < (size_t)height * width; ++i) {
+    volatile float t = mult * mat2[i % height + (size_t)height * (i / num_pix)];
+    mat1[i] += t;
+  }
+}
+
+void oracle_copy_transpose(const float* src, int rows, int cols, float* dst) {
+  for (int j = 0; j < cols; ++j)
+    for (int i = 0; i < rows; ++i) dst[(size_t)j + (size_t)cols * i] = src[(size_t)i + (size_t)rows * j];
+}
+
+int oracle_version(void) { return 2; }

@@ -272,6 +272,44 @@ void ref_sgd_step(float* grad, float* param, float* history, int rows, int cols,
   else if (norm_limit > 0) normlimit_by_axis(&p2, &p2, 1, norm_limit, 0);
 }
 
-int ref_version() { return 1; }
+// ---- input staging (eigenmat.cc:73,325-370,499-560,970-1005,1962-1988,2046-2090) ------------------------------
+// images: (dims, num_images) one case per column; patches: (num_images, colours*ph*pw) = CHWN batch
+int ref_extract_patches(float* images, int dims, int num_images, float* patches, float* wo, float* ho, float* flip, int img_w,
+                        int img_h, int pw, int ph) {
+  const int colors = dims / (img_w * img_h);
+  eigenmat im = wrap(images, dims, num_images), pt = wrap(patches, num_images, colors * pw * ph), w = wrap(wo, 1, num_images),
+           h = wrap(ho, 1, num_images), f = wrap(flip, 1, num_images);
+  return extract_patches(&im, &pt, &w, &h, &f, img_w, img_h, pw, ph);
+}
+int ref_shuffle_columns(float* mat, int rows, int cols, float* perm) {
+  eigenmat m = wrap(mat, rows, cols), p = wrap(perm, 1, cols);
+  return shuffleColumns(&m, &p);
+}
+int ref_add_col_mult(float* mat, int rows, int cols, float* vec, float mult) {
+  eigenmat m = wrap(mat, rows, cols), v = wrap(vec, rows, 1);
+  return add_col_mult(&m, &v, &m, mult);
+}
+int ref_div_by_col_vec(float* mat, int rows, int cols, float* vec) {
+  eigenmat m = wrap(mat, rows, cols), v = wrap(vec, rows, 1);
+  return div_by_col_vec(&m, &v, &m);
+}
+int ref_mult_by_row_vec(float* mat, int rows, int cols, float* vec) {
+  eigenmat m = wrap(mat, rows, cols), v = wrap(vec, 1, cols);
+  return mult_by_row_vec(&m, &v, &m);
+}
+int ref_normalize_columns(float* mat, int rows, int cols) {
+  eigenmat m = wrap(mat, rows, cols);
+  return normalize_by_axis(&m, &m, 0);
+}
+int ref_add_to_each_pixel(float* mat1, int rows, int cols, float* mat2, int colors, float mult) {
+  eigenmat a = wrap(mat1, rows, cols), b = wrap(mat2, rows, colors);
+  return add_to_each_pixel(&a, &b, &a, mult);
+}
+int ref_copy_transpose(float* src, int rows, int cols, float* dst) {
+  eigenmat a = wrap(src, rows, cols), b = wrap(dst, cols, rows);
+  return copy_transpose(&a, &b);
+}
+
+int ref_version() { return 2; }
 
 }  // extern "C"

@@ -56,6 +56,35 @@ def compute_all(R):
     g0, w0, h0 = inputs(403, (30, 12), (30, 12), (30, 12))
     R.sgd_step(g0, w0, h0, 5e-4, 0.9, 0.01, 0.7, 0.8, 0.0)
     out["sgd/grad"], out["sgd/param"], out["sgd/hist"] = g0, w0, h0
+    out.update(staging(R))
+    return out
+
+
+def staging_inputs():
+    """The DataHandler's GPU-side staging ops: 11 cases of 3 x 20 x 23 images, 13 x 16 patches."""
+    rng = np.random.default_rng(500)
+    n, colors, W, H, pw, ph = 11, 3, 23, 20, 16, 13
+    return dict(n=n, colors=colors, W=W, H=H, pw=pw, ph=ph,
+                images=rng.standard_normal((n, colors * H * W)).astype(np.float32),
+                wo=rng.integers(0, W - pw + 1, n).astype(np.float32), ho=rng.integers(0, H - ph + 1, n).astype(np.float32),
+                flip=(rng.random(n) > 0.5).astype(np.float32), perm=rng.permutation(n).astype(np.float32),
+                mean=rng.standard_normal(colors * H * W).astype(np.float32),
+                std=(rng.random(colors * H * W) + 0.5).astype(np.float32),
+                noise=rng.standard_normal((colors, n)).astype(np.float32), rowvec=rng.standard_normal(colors).astype(np.float32))
+
+
+def staging(R):
+    d = staging_inputs()
+    out = {}
+    out["staging/extract"] = R.extract_patches(d["images"], d["wo"], d["ho"], d["flip"], d["W"], d["H"], d["pw"], d["ph"])
+    out["staging/shuffle"] = R.shuffle_columns(d["images"].copy(), d["perm"])
+    m = R.add_col_mult(d["images"].copy(), d["mean"], -1.0)
+    out["staging/normalize"] = R.div_by_col_vec(m, d["std"])
+    out["staging/center"] = R.normalize_columns(d["images"].copy())
+    out["staging/transpose"] = R.copy_transpose(d["images"])
+    batch = out["staging/extract"].reshape(d["colors"] * d["ph"] * d["pw"], d["n"]).copy()    # (cols, rows) view of the CHWN batch
+    out["staging/pixel_noise"] = R.add_to_each_pixel(batch, d["noise"], 0.1)
+    out["staging/mult_row"] = R.mult_by_row_vec(d["noise"].copy(), d["rowvec"])
     return out
 
 

@@ -107,6 +107,53 @@ class HipImpl:
         Matrix.Dot(A, B, T, beta, alpha, a_trans, b_trans)   # (c, alpha=scale of c, beta=scale of product)
         return T.ToNumpy().reshape(target.shape)
 
+    # ---- input staging (numpy (cols, rows) <-> column-major Matrix) ----------------------------------------------
+    def extract_patches(self, images, wo, ho, flip, img_w, img_h, pw, ph):
+        n, dims = images.shape
+        colors = dims // (img_w * img_h)
+        src = _mat(images, dims, n)
+        dst = Matrix()
+        dst.AllocateGPUMemory(n, colors * ph * pw)
+        Matrix.ExtractPatches(src, dst, _mat(wo, 1, n), _mat(ho, 1, n), _mat(flip, 1, n), img_h, img_w, ph, pw)
+        return dst.ToNumpy().reshape(colors, ph, pw, n)
+
+    def shuffle_columns(self, mat, perm):
+        M = _mat(mat, mat.shape[1], mat.shape[0])
+        M.ShuffleColumns(_mat(perm, 1, perm.size))
+        return M.ToNumpy().reshape(mat.shape)
+
+    def add_col_mult(self, mat, vec, mult):
+        M = _mat(mat, mat.shape[1], mat.shape[0])
+        M.AddColVec(_mat(vec, vec.size, 1), mult)
+        return M.ToNumpy().reshape(mat.shape)
+
+    def div_by_col_vec(self, mat, vec):
+        M = _mat(mat, mat.shape[1], mat.shape[0])
+        M.DivideByColVec(_mat(vec, vec.size, 1))
+        return M.ToNumpy().reshape(mat.shape)
+
+    def mult_by_row_vec(self, mat, vec):
+        M = _mat(mat, mat.shape[1], mat.shape[0])
+        M.MultByRowVec(_mat(vec, 1, vec.size))
+        return M.ToNumpy().reshape(mat.shape)
+
+    def normalize_columns(self, mat):
+        M = _mat(mat, mat.shape[1], mat.shape[0])
+        M.NormalizeColumnwise()
+        return M.ToNumpy().reshape(mat.shape)
+
+    def add_to_each_pixel(self, mat1, mat2, mult):
+        M = _mat(mat1, mat1.shape[1], mat1.shape[0])
+        M.AddToEachPixel(_mat(mat2, mat2.shape[1], mat2.shape[0]), mult)
+        return M.ToNumpy().reshape(mat1.shape)
+
+    def copy_transpose(self, src):
+        S = _mat(src, src.shape[1], src.shape[0])
+        D = Matrix()
+        D.AllocateGPUMemory(src.shape[0], src.shape[1])
+        S.CopyTranspose(D)
+        return D.ToNumpy().reshape(src.shape[1], src.shape[0])
+
     def add_row_vec(self, mat, vec):
         M, V = _mat(mat, mat.shape[1], mat.shape[0]), _mat(vec, 1, vec.size)
         M.AddRowVec(V)

@@ -305,3 +305,26 @@ def test_conv_outp_bias_equals_outp_plus_two_step_sum(hip, g):
         assert rel_err(dw, oracle.port.conv_outp(g, x, dy, dw0.copy(), st, so)) < TOL
         ref_db = st * db0 + so * dy.reshape(g.F, -1).astype(np.float64).sum(axis=1)
         assert np.allclose(db, ref_db, rtol=2e-5, atol=1e-5 * np.abs(ref_db).max()), np.abs(db - ref_db).max()
+
+
+@pytest.mark.gpu
+def test_input_staging_is_bit_exact_vs_oracle_incl_ragged_sizes(hip):
+    """extract_patches / shuffleColumns / copy_transpose are byte moves and the col/row-vector ops single fp32
+    operations: bit-exact.  Sizes that are not multiples of the 32 x 32 transpose tile, flips on and off, crops at both
+    borders, an odd column count (the unpaired last index of shuffleColumns stays put)."""
+    rng = np.random.default_rng(31)
+    for n, colors, W, H, pw, ph in [(37, 3, 45, 41, 33, 32), (5, 1, 9, 9, 9, 9), (64, 3, 40, 40, 32, 32)]:
+        im = rng.standard_normal((n, colors * H * W)).astype(np.float32)
+        wo = rng.integers(0, W - pw + 1, n).astype(np.float32)
+        ho = rng.integers(0, H - ph + 1, n).astype(np.float32)
+        wo[0], ho[0] = W - pw, H - ph
+        fl = (rng.random(n) > 0.5).astype(np.float32)
+        assert np.array_equal(hip.extract_patches(im, wo, ho, fl, W, H, pw, ph), oracle.port.extract_patches(im, wo, ho, fl, W, H, pw, ph))
+        perm = rng.permutation(n).astype(np.float32)
+        assert np.array_equal(hip.shuffle_columns(im.copy(), perm), oracle.port.shuffle_columns(im.copy(), perm))
+        assert np.array_equal(hip.copy_transpose(im), im.T)
+        mean, std = rng.standard_normal(im.shape[1]).astype(np.float32), (rng.random(im.shape[1]) + 0.5).astype(np.float32)
+        assert np.array_equal(hip.div_by_col_vec(hip.add_col_mult(im.copy(), mean, -1.0), std),
+                              oracle.port.div_by_col_vec(oracle.port.add_col_mult(im.copy(), mean, -1.0), std))
+        got, ref = hip.normalize_columns(im.copy()), oracle.port.normalize_columns(im.copy())
+        assert np.allclose(got, ref, rtol=0, atol=1e-5)      # column mean: parallel vs sequential fp32 sum

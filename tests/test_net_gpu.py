@@ -263,3 +263,43 @@ def test_side_stream_updates_are_bit_identical_to_serial_updates(gpu):
             assert (off, n) == (off1, n1)   # the 128-float padding between slices is never written: skip it
             bad = np.flatnonzero(a[off:off + n] != b[off:off + n])
             assert bad.size == 0, (name, off, bad.size, bad[:8].tolist())
+
+
+@pytest.mark.gpu
+def test_chunk_datahandler_stages_batches_like_the_reference_pipeline(gpu):
+    """GPU-side input staging: chunk on the GPU as (dims, cases), per-batch random crop + flip +
+    transpose by extract_patches into the input layer, mean/std normalisation at load, in-place column shuffle at chunk
+    wrap with images and labels kept paired.  Labels are the case ids, so every staged image can be re-derived on the
+    CPU from the ORIGINAL chunk with the offsets the device sampled — across two shuffles."""
+    from convnet_amd.convnet import ConvNet
+    from convnet_amd.datahandler import ChunkDataHandler
+    rng = np.random.default_rng(3)
+    cases, colors, S, crop, bs = 21, 3, 41, 35, 8
+    images = rng.integers(0, 256, (cases, colors * S * S)).astype(np.float32)
+    labels = np.arange(cases, dtype=np.float32) % 10
+    ids = np.arange(cases, dtype=np.float32)
+    mean, std = rng.random(colors * S * S).astype(np.float32) * 255, (rng.random(colors * S * S).astype(np.float32) + 0.5) * 60
+    net = ConvNet(small_alexnet(), fused=True)
+    net.SetBatchsize(bs)
+    dh = ChunkDataHandler(images, ids, bs, S, crop, colors, translate=True, flip=True, mean=mean, std=std, randomize=True, seed=4)
+    net.SetupDataset(dh)
+    net.AllocateMemory(False)
+    normed = oracle.port.div_by_col_vec(oracle.port.add_col_mult(images.copy(), mean, -1.0), std)
+    seen = []
+    for step in range(7):      # 7 * 8 = 56 cases > 2 chunks: two shuffles
+        net.GetBatch(dh)
+        got = net.input_layers_[0].GetState().ToNumpy().reshape(colors, crop, crop, bs)
+        case = net.output_layers_[0].GetData().ToNumpy().reshape(-1).astype(int)
+        wo, ho, fl = (m.ToNumpy().reshape(-1) for m in (dh.width_offset_, dh.height_offset_, dh.flip_bit_))
+        assert (wo >= 0).all() and (wo < S - crop + 1).all() and (ho >= 0).all() and (ho < S - crop + 1).all()
+        ref = oracle.port.extract_patches(np.ascontiguousarray(normed[case]), wo, ho, fl, S, S, crop, crop)
+        assert np.array_equal(got, ref), step
+        seen.extend(case.tolist())
+    assert len(set(seen[:16])) == 16 and set(seen) == set(range(cases))     # a chunk pass never repeats a case
+    assert seen[:8] == list(range(8)) and sorted(seen[16:32]) != seen[16:32]  # first pass in order, later passes shuffled
+    # and a real training step runs off it
+    dh2 = ChunkDataHandler(images, labels, bs, S, crop, colors, mean=mean, std=std, seed=5)
+    net.SetupDataset(dh2)
+    for _ in range(3):
+        net.TrainOneBatch()
+    assert np.isfinite(net.parameters_.ToNumpy()).all()
