@@ -387,3 +387,43 @@ class ConvNet:
             self._in_train_step = False
         self.current_iter_ += 1
         return error
+
+    # ---- checkpoint / resume: src/convnet.cc:659-684,737-751 ------------------------------------------------------------
+    def ReduceLearningRate(self, factor):
+        # src/convnet.cc:826-830
+        for e in self.edges_:
+            if isinstance(e, EdgeWithWeight):
+                e.ReduceLearningRate(factor)
+
+    def GetCheckpointFilename(self):
+        # src/convnet.cc:651-657: <checkpoint_dir>/<name>_<timestamp>.h5
+        import os
+        m = self.model_
+        ts = m.timestamp[-1] if m.timestamp else ""
+        return os.path.join(m.checkpoint_dir, f"{m.name}_{ts}.h5")
+
+    def Save(self, output_file=None):
+        """HDF5 file in the reference's layout: every edge's weight / bias / gradient_history datasets and step attributes,
+        plus ``__lr_reduce_counter__`` and ``__current_iter__``; written to ``<name>temp`` and renamed (convnet.cc:666-684)."""
+        import os
+        from . import hdf5io
+        output_file = output_file or self.GetCheckpointFilename()
+        tmp = output_file + "temp"
+        with hdf5io.File(tmp, "w") as f:
+            for e in self.edges_:
+                e.SaveParameters(f)
+            f.WriteHDF5IntAttr("__lr_reduce_counter__", getattr(self, "lr_reduce_counter_", 0))
+            f.WriteHDF5IntAttr("__current_iter__", self.current_iter_)
+        os.replace(tmp, output_file)
+
+    def Load(self, input_file=None):
+        """Weights always; optimizer history + step only where the optimizer is allocated (a training net), so the same file
+        serves resume and fprop-only use (edge_with_weight.cc:42-58).  Learning-rate reductions are re-applied."""
+        from . import hdf5io
+        with hdf5io.File(input_file or self.GetCheckpointFilename()) as f:
+            for e in self.edges_:
+                e.LoadParameters(f)
+            self.lr_reduce_counter_ = f.ReadHDF5IntAttr("__lr_reduce_counter__", getattr(self, "lr_reduce_counter_", 0))
+            for _ in range(self.lr_reduce_counter_):
+                self.ReduceLearningRate(self.model_.reduce_lr_factor)
+            self.current_iter_ = f.ReadHDF5IntAttr("__current_iter__", self.current_iter_)

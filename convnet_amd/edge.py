@@ -114,6 +114,12 @@ class Edge:
     def UpdateWeights(self):
         pass
 
+    def SaveParameters(self, file):       # src/edge.cc: edges without parameters store nothing
+        pass
+
+    def LoadParameters(self, file, edge_name=None):
+        pass
+
     def NotifyStart(self):
         pass
 
@@ -235,6 +241,31 @@ class EdgeWithWeight(Edge):
         self.weight_optimizer_.ReduceLearningRate(factor)
         if self.bias_optimizer_:
             self.bias_optimizer_.ReduceLearningRate(factor)
+
+    def SaveParameters(self, file):
+        # src/edge_with_weight.cc:27-40: "<source>:<dest>:weight" / ":bias" + the optimizers' state under the same prefix
+        if self.is_tied_:
+            return
+        name = f"{self.source_node_}:{self.dest_node_}:weight"
+        self.weights_.WriteHDF5(file, name)
+        self.weight_optimizer_.SaveParameters(file, name)
+        if not self.has_no_bias_:
+            name = f"{self.source_node_}:{self.dest_node_}:bias"
+            self.bias_.WriteHDF5(file, name)
+            self.bias_optimizer_.SaveParameters(file, name)
+
+    def LoadParameters(self, file, edge_name=None):
+        # src/edge_with_weight.cc:42-64 (optimizer state only if the optimizer has been allocated, i.e. when training)
+        if self.is_tied_:
+            return
+        edge_name = edge_name or f"{self.source_node_}:{self.dest_node_}"
+        self.weights_.ReadHDF5(file, f"{edge_name}:weight")
+        if self.weight_optimizer_.IsAllocated():
+            self.weight_optimizer_.LoadParameters(file, f"{edge_name}:weight")
+        if not self.has_no_bias_:
+            self.bias_.ReadHDF5(file, f"{edge_name}:bias")
+            if self.bias_optimizer_.IsAllocated():
+                self.bias_optimizer_.LoadParameters(file, f"{edge_name}:bias")
 
     def UpdateWeights(self):
         # src/edge_with_weight.cc:96-106

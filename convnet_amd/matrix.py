@@ -210,6 +210,20 @@ class Matrix:
     def ToNumpy(self):
         return self.CopyToHost().copy()
 
+    # ---- HDF5 (src/matrix.cc:419-435): a column-major (rows, cols) matrix is a row-major (cols, rows) dataset ----------
+    def WriteHDF5(self, file, name):
+        h = self.CopyToHost()
+        file.WriteHDF5CPU(h, self.mat_.size[1], self.mat_.size[0], name)
+
+    def ReadHDF5(self, file, name):
+        self.GetHostData().reshape(-1)[:] = file.ReadHDF5CPU(self.GetNumEls(), name)
+        self.CopyToDevice()
+
+    def AllocateAndReadHDF5(self, file, name):
+        rows, cols = file.ReadHDF5Shape(name)
+        self.AllocateGPUMemory(rows, cols)
+        self.ReadHDF5(file, name)
+
     def ReadValue(self, *idx):
         row, col = idx if len(idx) == 2 else (idx[0] % self.mat_.size[0], idx[0] // self.mat_.size[0])
         err = ctypes.c_int(0)

@@ -65,6 +65,12 @@ class Optimizer:
     def IsAllocated(self):
         return False
 
+    def LoadParameters(self, file, prefix):     # src/optimizer.cc:110-111: the base class stores nothing
+        pass
+
+    def SaveParameters(self, file, prefix):
+        pass
+
 
 class SGDOptimizer(Optimizer):
     def __init__(self, c):
@@ -89,6 +95,16 @@ class SGDOptimizer(Optimizer):
 
     def IsAllocated(self):
         return self.gradient_history_.GetNumEls() > 0
+
+    def LoadParameters(self, file, prefix):
+        # src/optimizer.cc:138-146
+        self.gradient_history_.ReadHDF5(file, f"{prefix}_gradient_history")
+        self.step_ = file.ReadHDF5IntAttr(f"{prefix}_step", self.step_)
+
+    def SaveParameters(self, file, prefix):
+        # src/optimizer.cc:148-156
+        self.gradient_history_.WriteHDF5(file, f"{prefix}_gradient_history")
+        file.WriteHDF5IntAttr(f"{prefix}_step", self.step_)
 
     def GetMomentum(self):
         # src/optimizer.cc:158-165

@@ -93,3 +93,30 @@ def test_sgd_schedules():
     assert o.GetDecayedEpsilon() == 0.5
     o.step_ = 1000
     assert o.GetDecayedEpsilon() == 0.2
+
+
+def test_hdf5_io_layout_and_reference_written_file(tmp_path):
+    """The HDF5 layer without a GPU: dataset shape convention (a column-major (rows, cols) matrix is a
+    row-major (cols, rows) dataset, util.cc:128-175), int attributes, missing-attribute default, size mismatch; and, when
+    the reference tree is mounted, a file the reference's own tools wrote (examples/imagenet/pixel_mean.h5)."""
+    import numpy as np
+    from convnet_amd import hdf5io
+    p = str(tmp_path / "t.h5")
+    a = np.arange(12, dtype=np.float32)
+    with hdf5io.File(p, "w") as f:
+        f.WriteHDF5CPU(a, 4, 3, "x:y:weight")          # Matrix(rows=3, cols=4).WriteHDF5 passes (size[1], size[0])
+        f.WriteHDF5IntAttr("x:y:weight_step", 41)
+    with hdf5io.File(p) as f:
+        assert f.ReadHDF5Shape("x:y:weight") == (3, 4) and f.Has("x:y:weight") and not f.Has("x:y:bias")
+        assert np.array_equal(f.ReadHDF5CPU(12, "x:y:weight"), a)
+        assert f.ReadHDF5IntAttr("x:y:weight_step", 0) == 41 and f.ReadHDF5IntAttr("__current_iter__", 7) == 7
+        with pytest.raises(ValueError):
+            f.ReadHDF5CPU(11, "x:y:weight")
+        with pytest.raises(KeyError):
+            f.ReadHDF5Shape("nope")
+    ref = os.path.join(REF, "imagenet/pixel_mean.h5")
+    if os.path.exists(ref):
+        with hdf5io.File(ref) as f:
+            assert f.ReadHDF5Shape("pixel_mean") == (1, 3)
+            assert np.allclose(f.ReadHDF5CPU(3, "pixel_mean"), [122.77497, 115.91181, 102.984184], rtol=1e-6)
+            assert np.allclose(f.ReadHDF5CPU(3, "pixel_std"), [70.58011, 68.60053, 72.02416], rtol=1e-6)

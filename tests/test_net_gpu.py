@@ -303,3 +303,46 @@ def test_chunk_datahandler_stages_batches_like_the_reference_pipeline(gpu):
     for _ in range(3):
         net.TrainOneBatch()
     assert np.isfinite(net.parameters_.ToNumpy()).all()
+
+
+@pytest.mark.gpu
+def test_hdf5_checkpoint_resume_is_bit_exact_and_uses_the_reference_layout(gpu, tmp_path):
+    """ConvNet::Save / Load (src/convnet.cc:666-684,737-751): train 3 steps, save, load into a differently initialised
+    net, continue both for 2 steps on the same data -> bit-identical parameters, momentum history, iteration and
+    optimizer step counters.  Dataset / attribute names are the reference's."""
+    from convnet_amd import hdf5io
+    a = build(small_alexnet(), 16, fused=True, seed_data=9)
+    for _ in range(3):
+        a.TrainOneBatch()
+    path = str(tmp_path / "ckpt.h5")
+    a.Save(path)
+    with hdf5io.File(path) as f:
+        e = a.GetEdgeByName("input:c1")
+        assert f.ReadHDF5Shape("input:c1:weight") == (e.GetWeight().GetRows(), e.GetWeight().GetCols())
+        assert f.Has("input:c1:bias") and f.Has("input:c1:weight_gradient_history") and f.Has("f7:output:bias_gradient_history")
+        assert f.ReadHDF5IntAttr("input:c1:weight_step", -1) == 3 and f.ReadHDF5IntAttr("__current_iter__", -1) == 3
+        assert f.ReadHDF5IntAttr("__lr_reduce_counter__", -1) == 0
+        assert np.array_equal(f.ReadHDF5CPU(e.GetWeight().GetNumEls(), "input:c1:weight"), e.GetWeight().ToNumpy().reshape(-1))
+    b = build(small_alexnet(), 16, fused=True, seed_data=9)
+    b.parameters_.Mult(0.5)            # make sure Load really overwrites
+    b.Load(path)
+    assert b.current_iter_ == 3 and b.GetEdgeByName("f6:f7").weight_optimizer_.step_ == 3
+    for net in (a, b):
+        net.train_dataset_.pos_ = 0
+        for _ in range(2):
+            net.TrainOneBatch()
+    for ea, eb in zip(a.edges_, b.edges_):
+        if ea.GetParameterMemoryRequirement():
+            assert np.array_equal(ea.GetWeight().ToNumpy(), eb.GetWeight().ToNumpy()), ea.GetName()
+            assert np.array_equal(ea.GetBias().ToNumpy(), eb.GetBias().ToNumpy()), ea.GetName()
+            assert np.array_equal(ea.weight_optimizer_.gradient_history_.ToNumpy(), eb.weight_optimizer_.gradient_history_.ToNumpy())
+    # an fprop-only net (no optimizer state allocated) loads the same file
+    from convnet_amd.convnet import ConvNet
+    from convnet_amd.datahandler import SyntheticDataHandler
+    c = ConvNet(small_alexnet(), fused=True)
+    c.SetBatchsize(16)
+    c.SetupDataset(SyntheticDataHandler(c, 16, seed=9, num_batches=1))
+    c.AllocateMemory(True)
+    c.Load(path)
+    assert np.array_equal(c.GetEdgeByName("c4:c5").GetWeight().ToNumpy(), np.asarray(hdf5io.File(path).ReadHDF5CPU(
+        c.GetEdgeByName("c4:c5").GetWeight().GetNumEls(), "c4:c5:weight")).reshape(c.GetEdgeByName("c4:c5").GetWeight().ToNumpy().shape))
