@@ -24,9 +24,10 @@ from . import pbtxt
 from .edge import ConvEdge, Edge, EdgeWithWeight, FCEdge, ResponseNormEdge
 from .layer import Layer, SoftmaxLayer
 from .matrix import Matrix
+from .trainer import TrainLoopMixin
 
 
-class ConvNet:
+class ConvNet(TrainLoopMixin):
     def __init__(self, model, fused=False, process_id=0, num_processes=1, verbose=False, exchange=None, overlap_update=None):
         """``model``: path to a pbtxt file, pbtxt text, or a parsed pbtxt.Model.
         ``overlap_update`` (default off): inside TrainOneBatch each edge's optimizer step is enqueued on a second

@@ -119,6 +119,14 @@ class GradientExchange:
                     t.div_(self.world_)
             self.done_events_[i] = None
 
+    def SumScalars(self, values):
+        """ConvNet::Accumulate(train_error, MPITAG_TRAINERROR) (src/convnet.cc:939): the per-rank training-accuracy counts
+        summed over ranks for the log line."""
+        dev = "cuda" if self.comm_stream_ is not None else "cpu"
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.tolist()
+
     def BucketState(self, edge):
         """"pending" while the edge's bucket has not been handed to RCCL yet; afterwards the event that
         fires when its all-reduce is complete (None if the exchange ran synchronously or the edge has no

@@ -34,6 +34,15 @@ class SyntheticDataHandler:
     def GetBatchSize(self):
         return self.batch_size_
 
+    def GetDataSetSize(self):
+        return self.batch_size_ * len(self.batches_)
+
+    def Seek(self, row):
+        self.pos_ = row // self.batch_size_
+
+    def Sync(self):
+        pass
+
     def GetBatch(self, data_layers):
         b = self.batches_[self.pos_ % len(self.batches_)]
         self.pos_ += 1
@@ -63,14 +72,21 @@ class ChunkDataHandler:
         self.image_size_, self.gpu_image_size_ = image_size, crop_size or image_size
         self.colors_, self.translate_, self.flip_, self.randomize_ = colors, translate, flip, randomize
         self.rng_ = np.random.default_rng(seed)
+        # Sequential (non-shuffled) use — validation, feature extraction — reads the dataset round-robin, so the batch that
+        # straddles the end continues with the first cases (the reference's chunk loader wraps the same way): keep a copy
+        # of the first batch_size cases behind the last one so that window is one contiguous slice.
+        pad = 0 if randomize else batch_size
+        if pad:
+            images = np.concatenate([images, images[:pad]], axis=0)
+            labels = np.concatenate([np.asarray(labels).reshape(-1), np.asarray(labels).reshape(-1)[:pad]])
         self.data_ = Matrix()
-        self.data_.AllocateGPUMemory(dims, self.chunk_size_)
+        self.data_.AllocateGPUMemory(dims, self.chunk_size_ + pad)
         self.data_.FromNumpy(images)                       # numpy (cases, dims) = column-major (dims, cases)
         if mean is not None:                               # DataIterator::Preprocess: m.AddColVec(mean_, -1); m.DivideByColVec(std_)
             self.data_.AddColVec(self._colvec(mean, dims), -1)
             self.data_.DivideByColVec(self._colvec(std, dims))
         self.labels_ = Matrix()
-        self.labels_.AllocateGPUMemory(1, self.chunk_size_)
+        self.labels_.AllocateGPUMemory(1, self.chunk_size_ + pad)
         self.labels_.FromNumpy(np.asarray(labels, np.float32).reshape(-1))
         self.perm_ = Matrix()
         self.perm_.AllocateGPUMemory(1, self.chunk_size_)
@@ -91,6 +107,15 @@ class ChunkDataHandler:
 
     def GetBatchSize(self):
         return self.batch_size_
+
+    def GetDataSetSize(self):
+        return self.chunk_size_
+
+    def Seek(self, row):
+        self.start_ = row
+
+    def Sync(self):
+        pass
 
     def _jitter(self):
         return self.image_size_ != self.gpu_image_size_ or self.flip_
@@ -122,11 +147,10 @@ class ChunkDataHandler:
 
     def GetBatch(self, data_layers):
         end = self.start_ + self.batch_size_
-        if end > self.chunk_size_:
-            if self.randomize_:
-                self.ShuffleIndices()
-                self.data_.ShuffleColumns(self.perm_)
-                self.labels_.ShuffleColumns(self.perm_)
+        if end > self.chunk_size_ and self.randomize_:     # DataHandler::GetBatch :147-166: drop the tail, reshuffle, restart
+            self.ShuffleIndices()
+            self.data_.ShuffleColumns(self.perm_)
+            self.labels_.ShuffleColumns(self.perm_)
             self.start_, end = 0, self.batch_size_
         self.SampleNoise()
         for l in data_layers:
@@ -141,4 +165,4 @@ class ChunkDataHandler:
             else:
                 self.labels_.GetSlice(self.label_slice_, self.start_, end)
                 self.label_slice_.CopyTranspose(l.GetData())
-        self.start_ = end
+        self.start_ = end % self.chunk_size_ if not self.randomize_ else end

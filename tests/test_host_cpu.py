@@ -120,3 +120,16 @@ def test_hdf5_io_layout_and_reference_written_file(tmp_path):
             assert f.ReadHDF5Shape("pixel_mean") == (1, 3)
             assert np.allclose(f.ReadHDF5CPU(3, "pixel_mean"), [122.77497, 115.91181, 102.984184], rtol=1e-6)
             assert np.allclose(f.ReadHDF5CPU(3, "pixel_std"), [70.58011, 68.60053, 72.02416], rtol=1e-6)
+
+
+def test_check_reduce_learning_rate_follows_the_reference_rule():
+    """src/convnet.cc:788-817: compare the means of the older and the newer half of the last reduce_lr_num_steps
+    validation values; reduce when the improvement is below reduce_lr_threshold."""
+    text = models.mnist_conv().replace("print_after: 100", "print_after: 100\nreduce_lr_num_steps: 4\nreduce_lr_threshold: 0.01")
+    net = ConvNet(text)
+    assert not net.CheckReduceLearningRate([0.1, 0.2, 0.3])                       # fewer than num_steps values
+    assert not net.CheckReduceLearningRate([0.1, 0.2, 0.3, 0.4])                  # accuracy still rising (0.15 -> 0.35)
+    assert net.CheckReduceLearningRate([0.0, 0.5, 0.50, 0.51, 0.505, 0.507])      # last four: 0.505 -> 0.506: flat
+    assert net.CheckReduceLearningRate([0.6, 0.6, 0.5, 0.5])                      # got worse
+    net.model_.smaller_is_better = True
+    assert not net.CheckReduceLearningRate([0.6, 0.6, 0.5, 0.5])                  # an error metric that still falls

@@ -6,6 +6,8 @@
    LeNet-5-class (avg-pool) and an AlexNet-shaped net with response norm.
  * one SGD step leaves parameters equal between fused/unfused; training reduces the loss.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -346,3 +348,74 @@ def test_hdf5_checkpoint_resume_is_bit_exact_and_uses_the_reference_layout(gpu, 
     c.Load(path)
     assert np.array_equal(c.GetEdgeByName("c4:c5").GetWeight().ToNumpy(), np.asarray(hdf5io.File(path).ReadHDF5CPU(
         c.GetEdgeByName("c4:c5").GetWeight().GetNumEls(), "c4:c5:weight")).reshape(c.GetEdgeByName("c4:c5").GetWeight().ToNumpy().shape))
+
+
+@pytest.mark.gpu
+def test_train_loop_validate_polyak_lr_schedule_checkpoint_and_feature_extraction(gpu, tmp_path):
+    """ConvNet::Train / Validate / ExtractFeatures (src/convnet.cc:571-657,866-1011) on a tiny net: cadence of the
+    train / validation log, Polyak queue, learning-rate cut on a flat validation curve, checkpoint + resume from
+    __current_iter__, and the (cases, dims) feature file."""
+    from convnet_amd import hdf5io
+    from convnet_amd.convnet import ConvNet
+    from convnet_amd.datahandler import ChunkDataHandler
+    extra = (f'print_after: 5\nvalidate_after: 10\nsave_after: 20\nreduce_lr_factor: 0.5\nreduce_lr_num_steps: 2\nreduce_lr_max: 3\n'
+             f'reduce_lr_threshold: 1.0\npolyak_after: 2\npolyak_queue_size: 3\ncheckpoint_dir: "{tmp_path}"\ntimestamp: "t0"')
+    text = small_alexnet().replace("print_after: 100", extra)
+    rng = np.random.default_rng(2)
+    S, colors, bs = 35, 3, 16
+    def data(cases, seed, randomize=False):
+        r = np.random.default_rng(seed)
+        return ChunkDataHandler(r.standard_normal((cases, colors * S * S)).astype(np.float32), r.integers(0, 10, cases), bs, S, S, colors,
+                                translate=False, flip=False, randomize=randomize, seed=seed)
+    net = ConvNet(text, fused=True)
+    net.SetBatchsize(bs)
+    net.SetupDataset(data(64, 1, True))
+    net.SetupValidationDataset(data(40, 2))
+    net.AllocateMemory(False)
+    lines = []
+    eps0 = net.GetEdgeByName("f6:f7").weight_optimizer_.epsilon_
+    hist = net.Train(max_iter=30, log=lines.append)
+    assert [t[0] for t in hist["train"]] == [5, 10, 15, 20, 25, 30] and all(0.0 <= t[1] <= 1.0 for t in hist["train"])
+    assert [v[0] for v in hist["val"]] == [10, 20, 30] and all(0.0 <= v[1] <= 1.0 for v in hist["val"])
+    # threshold 1.0 makes every comparison "flat": the first qualifying validation (2 values, step 20) arms, step 30 cuts
+    assert hist["lr_reductions"] == 1 and net.lr_reduce_counter_ == 1
+    assert net.GetEdgeByName("f6:f7").weight_optimizer_.epsilon_ == pytest.approx(eps0 * 0.5)
+    assert net.polyak_queue_full_ and len(net.polyak_parameters_) == 3
+    ckpt = net.GetCheckpointFilename()
+    assert ckpt.endswith("tiny_alex_t0.h5") and os.path.exists(ckpt)
+    with hdf5io.File(ckpt) as f:
+        assert f.ReadHDF5IntAttr("__current_iter__", -1) == 30 and f.ReadHDF5IntAttr("__lr_reduce_counter__", -1) == 1
+    # resume: a fresh net picks up iteration, optimizer steps and the reduced learning rate, and trains on
+    net2 = ConvNet(text, fused=True)
+    net2.SetBatchsize(bs)
+    net2.SetupDataset(data(64, 1, True))
+    net2.AllocateMemory(False)
+    net2.Load()
+    assert net2.current_iter_ == 30 and net2.GetEdgeByName("f6:f7").weight_optimizer_.epsilon_ == pytest.approx(eps0 * 0.5)
+    assert np.array_equal(net2.GetEdgeByName("c4:c5").GetWeight().ToNumpy(), net.GetEdgeByName("c4:c5").GetWeight().ToNumpy())
+    hist2 = net2.Train(max_iter=35, log=lines.append, checkpoint=False)
+    assert [t[0] for t in hist2["train"]] == [35] and net2.current_iter_ == 35
+    # validation is deterministic and leaves the weights alone
+    v1, v2 = net2.Validate(data(40, 2)), net2.Validate(data(40, 2))
+    assert v1 == v2 and len(v1) == 1
+    # features: 40 cases through batches of 16 (last batch contributes 8), one case per row
+    out = str(tmp_path / "feat.h5")
+    val = data(40, 2)
+    net2.ExtractFeatures(val, ["f7", "output"], out)
+    with hdf5io.File(out) as f:
+        assert f.ReadHDF5Shape("f7") == (40, 40) and f.ReadHDF5Shape("output") == (10, 40)    # (dims, cases) column-major view
+        probs = f.ReadHDF5CPU(400, "output").reshape(40, 10)
+    assert np.allclose(probs.sum(axis=1), 1.0, atol=1e-5)
+    val.Seek(0)
+    for l in net2.layers_:
+        l.ResetAddOrOverwrite()
+    val.GetBatch(net2.data_layers_)
+    net2.Fprop(False)
+    assert np.array_equal(probs[:16], net2.GetLayerByName("output").GetState().ToNumpy().T)
+    val.Seek(32)               # the straddling batch: cases 32..39 then 0..7
+    for l in net2.layers_:
+        l.ResetAddOrOverwrite()
+    val.GetBatch(net2.data_layers_)
+    net2.Fprop(False)
+    last = net2.GetLayerByName("output").GetState().ToNumpy().T
+    assert np.array_equal(probs[32:], last[:8]) and np.array_equal(probs[:8], last[8:])
