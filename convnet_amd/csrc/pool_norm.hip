@@ -6,6 +6,7 @@
 // output element, float4 in / float4 out, no atomics), so the traffic is the algorithmic
 // read-once/write-once bytes plus L2-absorbed window overlap.
 #include <cfloat>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -598,13 +599,17 @@ static void rnorm_fwd_impl(cudamat* images, cudamat* targets, int numFilters, in
   KernelTimer timer("rnorm_fwd_kernel", "rnorm_fwd", 0.0, 8.0 * total);
   {
     const int C = numFilters;
-    const int LT = C <= 192 ? 64 : (C <= 384 ? 32 : (C <= 768 ? 16 : 0));
+    int LT = C <= 192 ? 64 : (C <= 384 ? 32 : (C <= 768 ? 16 : 0));
+    if (const char* f = getenv("CONVNET_RNORM_FWD_LT")) LT = atoi(f);   // tuning knob (tools/pool_bench.py)
     if (LT) {   // LDS-tiled, read-once/write-once
       const size_t smem = sizeof(float) * (size_t)C * LT;
       const dim3 grid((unsigned)((locs + LT - 1) / LT)), block(256);
-      if (LT == 64) hipLaunchKernelGGL(rnorm_fwd_lds_kernel<64>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec, relu);
-      else if (LT == 32) hipLaunchKernelGGL(rnorm_fwd_lds_kernel<32>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec, relu);
-      else hipLaunchKernelGGL(rnorm_fwd_lds_kernel<16>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec, relu);
+#define RN_FWD(L) hipLaunchKernelGGL(rnorm_fwd_lds_kernel<L>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec, relu)
+      if (LT == 64) RN_FWD(64);
+      else if (LT == 32) RN_FWD(32);
+      else if (LT == 16) RN_FWD(16);
+      else RN_FWD(8);
+#undef RN_FWD
       return;
     }
   }
@@ -630,15 +635,28 @@ void ResponseNormCrossMapUndoGemm(cudamat* outGrads, cudamat* inputs, cudamat* t
   const size_t locs = total / numFilters;
   {
     const int C = numFilters;
-    const int LT = C <= 64 ? 64 : (C <= 128 ? 32 : (C <= 256 ? 16 : 0));
+    // measured (N=256): C=96 LT 8/16/32 -> 484/291/324 us, C=256 LT 8/16/32 -> 104/83/166 us: more, smaller blocks per CU
+    // (the three phases of a block do not overlap) beat longer contiguous rows
+    int LT = C <= 64 ? 64 : (C <= 256 ? 16 : (C <= 512 ? 8 : 0));
+    if (const char* f = getenv("CONVNET_RNORM_UNDO_LT")) LT = atoi(f);   // tuning knob (tools/pool_bench.py)
     if (LT) {
       const bool vec = locs % 4 == 0 && a16(outGrads->data_device) && a16(inputs->data_device) && a16(targets->data_device);
       KernelTimer timer("rnorm_undo_kernels", "rnorm_undo", 0.0, 12.0 * total);
       const size_t smem = sizeof(float) * 3 * (size_t)C * LT;
       const dim3 grid((unsigned)((locs + LT - 1) / LT)), block(256);
-      if (LT == 64) hipLaunchKernelGGL(rnorm_undo_lds_kernel<64>, grid, block, smem, stream(), outGrads->data_device, inputs->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec);
-      else if (LT == 32) hipLaunchKernelGGL(rnorm_undo_lds_kernel<32>, grid, block, smem, stream(), outGrads->data_device, inputs->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec);
-      else hipLaunchKernelGGL(rnorm_undo_lds_kernel<16>, grid, block, smem, stream(), outGrads->data_device, inputs->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec);
+      CHIP_REQUIRE(smem <= 160 * 1024);
+#define RN_UNDO(L)                                                                                                              \
+  do {                                                                                                                          \
+    if (smem > 64 * 1024)   /* >64 KiB of dynamic LDS needs an explicit opt-in */                                                \
+      CHIP_CHECK(hipFuncSetAttribute((const void*)rnorm_undo_lds_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+    hipLaunchKernelGGL(rnorm_undo_lds_kernel<L>, grid, block, smem, stream(), outGrads->data_device, inputs->data_device,       \
+                       targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec);                                  \
+  } while (0)
+      if (LT == 64) RN_UNDO(64);
+      else if (LT == 32) RN_UNDO(32);
+      else if (LT == 16) RN_UNDO(16);
+      else RN_UNDO(8);
+#undef RN_UNDO
       return;
     }
   }
