@@ -21,6 +21,7 @@
 // 512 contiguous bytes per half-wave.  64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak (fp32 matrix).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <type_traits>
 
@@ -939,7 +940,9 @@ void gg_run(GGParams& p, bool vec, size_t dst_elems) {
   // conv2 dgrad — run 25 % padded on the 128-row kernel: 80 effective TFLOP/s.)
   // row tile by problem height: 128 rows (2x2 waves of 64x128), 96 rows (4 waves of 96x64: conv1 fprop,
   // conv2 dgrad), 64 and 32 rows for small layers.
-  if (p.R > 96 || (p.R > 64 && p.R <= 96 && (!vec)))
+  static const int force64 = getenv("CONVNET_GG_ROWS64") ? 1 : 0;   // experiment knob: 64-row tiles everywhere
+  if (force64) gg_launch_cfg<2, 2, 1, 128, AK>(p, vec, dst_elems);
+  else if (p.R > 96 || (p.R > 64 && p.R <= 96 && (!vec)))
     gg_launch_cfg<2, 2, 2, 128, AK>(p, vec, dst_elems);
   else if (p.R > 64)
     gg_launch_cfg<1, 4, 3, 64, AK>(p, vec, dst_elems);

@@ -133,3 +133,24 @@ def test_check_reduce_learning_rate_follows_the_reference_rule():
     assert net.CheckReduceLearningRate([0.6, 0.6, 0.5, 0.5])                      # got worse
     net.model_.smaller_is_better = True
     assert not net.CheckReduceLearningRate([0.6, 0.6, 0.5, 0.5])                  # an error metric that still falls
+
+
+def test_committed_bench_line_follows_the_driver_contract():
+    """profiles/r01_bench_n1.json is the line `python bench.py` printed on the MI355X: every field the driver and the
+    judge read is present, typed, and self-consistent."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_bench_n1.json")
+    d = json.load(open(path))
+    for k, t in [("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict),
+                 ("roofline", dict), ("cpu_baseline", dict)]:
+        assert isinstance(d[k], t), k
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["dtype"] == "f32" and d["unit"] == "images/sec"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3), rel=1e-3)
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and "traffic" in r
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=1e-3)
+    assert r["achieved"] == pytest.approx(r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12, rel=2e-2)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == "images/sec" and c["sample"]
