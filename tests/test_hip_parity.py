@@ -71,6 +71,7 @@ CONV_CASES = [
     Geom(N=132, C=16, H=7, W=7, F=40, Ky=3, Kx=3, pady=1, padx=1),                     # N just over one 128 block
     Geom(N=4, C=8, H=9, W=9, F=200, Ky=3, Kx=3, sy=3, sx=3),                            # stride == kernel
     Geom(N=4, C=8, H=10, W=10, F=33, Ky=2, Kx=2, sy=3, sx=3),                           # stride > kernel (uncovered pixels)
+    Geom(N=6, C=3, H=21, W=19, F=96, Ky=7, Kx=7, sy=2, sx=2, pady=1, padx=1),          # conv1 shape, N%4!=0: scalar path of the 16x16 wgrad tile
 ]
 
 
@@ -289,7 +290,7 @@ def test_event_trio_orders_two_streams(hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("g", [CONV_CASES[0], CONV_CASES[1], CONV_CASES[4], CONV_CASES[5], CONV_CASES[6]],
+@pytest.mark.parametrize("g", [CONV_CASES[0], CONV_CASES[1], CONV_CASES[4], CONV_CASES[5], CONV_CASES[6], CONV_CASES[10]],
                          ids=lambda g: f"N{g.N}C{g.C}F{g.F}K{g.K}")
 def test_conv_outp_bias_equals_outp_plus_two_step_sum(hip, g):
     """convOutpBias = convOutp + the shared-bias gradient (conv_edge.cc:210-221), whether the bias row rides in the
