@@ -59,6 +59,12 @@ struct GGParams {
   int relu;
   const float* mask;  // nullable; same layout as dst: out = mask > 0 ? out * post_scale : 0  (fused ReLU' [+dropout'])
   float post_scale;
+  // Tail split (tail_splits > 1): tiles [0, tail_first) are whole-K blocks that fill complete rounds of the resident
+  // block slots; the remaining tiles — the partial last round — are each cut into tail_splits K-ranges so the last round
+  // is full too.  Their raw accumulators go to tail_partial in register order and gg_tail_fix_kernel sums them and runs
+  // the normal epilogue.  Block b: XCD k = b & 7 does its run of tail_tf8 full tiles, then its tail_tt8 tail pieces.
+  int tail_first, tail_splits, tail_cps, tail_tf8, tail_tt8;
+  float* tail_partial;
 };
 
 // A strided dgrad is one gather-GEMM per stride class (conv_down_impl); the classes differ only in the fields
@@ -95,6 +101,83 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
   return (b & 7) * per + (b >> 3);
 }
 
+// The write-out of one block tile: accumulate into / overwrite the destination with the fused bias, ReLU and mask
+// options (fin), or store the raw sums into this split's slab.  Shared by gg_kernel and gg_tail_fix_kernel.
+template <int WR, int WC, int MT, int CW, bool VEC>
+__device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT][CW / 32], int row_tile, int col_tile, int split,
+                                            int pncols, int pGX, int pdy0, int pdx0) {
+  constexpr int NTC = CW / 32;
+  using fvec = __attribute__((ext_vector_type(NTC))) float;
+  constexpr int ROWS = WR * MT * 32;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave / WC, wc = wave % WC;
+  const int li = lane & 31, lh = lane >> 5;
+  const int r0 = row_tile * ROWS;
+  const int N = p.N;
+  const int colid = col_tile * WC + wc;
+  if (colid >= pncols) return;
+  const int m = colid / p.nblk, blk = colid - m * p.nblk;
+  const int oy = m / pGX, ox = m - oy * pGX;
+  const int dpix = (oy * p.dsy + pdy0) * p.DW + ox * p.dsx + pdx0;
+  const int n = blk * CW + NTC * li;
+  if (n >= N) return;
+  float* base = (p.splits > 1 ? p.partial + (size_t)split * p.slab : p.dst) + (size_t)dpix * N + n;
+  const bool fin = p.splits == 1;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = r0 + wr * MT * 32 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+      if (row >= p.R) continue;
+      fvec v;
+#pragma unroll
+      for (int u = 0; u < NTC; ++u) v[u] = acc[t][u][reg];
+      float* dp = base + (size_t)row * p.DP * N;
+      if (fin) {
+        const float bv = p.bias ? p.bias[row] : 0.f;
+        if (VEC) {
+          if (p.scaleTargets != 0.f) {
+            const fvec o = *reinterpret_cast<const fvec*>(dp);
+            v = p.scaleTargets * o + v;
+          }
+          v = v + bv;
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < NTC; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          if (p.mask) {
+            const fvec mk = *reinterpret_cast<const fvec*>(p.mask + (dp - p.dst));
+#pragma unroll
+            for (int e = 0; e < NTC; ++e) v[e] = mk[e] > 0.f ? v[e] * p.post_scale : 0.f;
+          }
+          *reinterpret_cast<fvec*>(dp) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < NTC; ++e) {
+            if (n + e < N) {
+              float x = v[e];
+              if (p.scaleTargets != 0.f) x = p.scaleTargets * dp[e] + x;
+              x += bv;
+              if (p.relu) x = x > 0.f ? x : 0.f;
+              if (p.mask) x = p.mask[(dp - p.dst) + e] > 0.f ? x * p.post_scale : 0.f;
+              dp[e] = x;
+            }
+          }
+        }
+      } else {
+        if (VEC) {
+          *reinterpret_cast<fvec*>(dp) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < NTC; ++e)
+            if (n + e < N) dp[e] = v[e];
+        }
+      }
+    }
+  }
+}
+
 // CW = images per wave-column (128: 4 interleaved 32-image MFMA column tiles per wave, ds_read_b128;
 // 64: 2 tiles, ds_read_b64 — used with MT=3 so a 96-row problem (conv1 fprop, conv2 dgrad) fills its tile).
 template <int WR, int WC, int MT, int CW, bool A_KCONTIG, bool VEC>
@@ -117,7 +200,7 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
   const float* pA = p.A;
   int pK = p.K, pGX = p.GX, pG = p.G, pTX = p.TX, pTYX = p.TYX, py0 = p.y0, px0 = p.x0, pdy0 = p.dy0, pdx0 = p.dx0, pncols = p.ncols,
       pcol_tiles = p.col_tiles;
-  int L;
+  int L, tsplit = -1;   // tsplit >= 0: this block computes one K-range of a tail tile
   if (ct.n > 0) {
     const int b = blockIdx.x;
     if (b >= ct.c[ct.n - 1].tile_end) return;
@@ -127,6 +210,16 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
     const GGClass& k = ct.c[c];
     pA = k.A; pK = k.K; pGX = k.GX; pG = k.G; pTX = k.TX; pTYX = k.TYX;
     py0 = k.y0; px0 = k.x0; pdy0 = k.dy0; pdx0 = k.dx0; pncols = k.ncols; pcol_tiles = k.col_tiles;
+  } else if (p.tail_splits > 1) {
+    const int k = blockIdx.x & 7, i = blockIdx.x >> 3;
+    if (i < p.tail_tf8) {
+      L = k * p.tail_tf8 + i;
+    } else {
+      const int j = k * p.tail_tt8 + (i - p.tail_tf8);
+      if (j >= (p.row_tiles * pcol_tiles - p.tail_first) * p.tail_splits) return;
+      L = p.tail_first + j / p.tail_splits;
+      tsplit = j % p.tail_splits;
+    }
   } else {
     const int tiles = p.row_tiles * pcol_tiles;
     const int per = (tiles + 7) >> 3;
@@ -163,8 +256,9 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
     b_lds[it] = (wcol * BK + krow) * CW + 4 * c4;
   }
 
-  const int kbeg = split * p.chunks_per_split * BK;
-  int kend = kbeg + p.chunks_per_split * BK;
+  const int cps = tsplit >= 0 ? p.tail_cps : p.chunks_per_split;
+  const int kbeg = (tsplit >= 0 ? tsplit : split) * cps * BK;
+  int kend = kbeg + cps * BK;
   if (kend > pK) kend = pK;
   const int nchunks = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
 
@@ -439,67 +533,42 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------
-  const int colid = col_tile * WC + wc;
-  if (colid >= pncols) return;
-  const int m = colid / p.nblk, blk = colid - m * p.nblk;
-  const int oy = m / pGX, ox = m - oy * pGX;
-  const int dpix = (oy * p.dsy + pdy0) * p.DW + ox * p.dsx + pdx0;
-  const int n = blk * CW + NTC * li;
-  if (n >= N) return;
-  float* base = (p.splits > 1 ? p.partial + (size_t)split * p.slab : p.dst) + (size_t)dpix * N + n;
-  const bool fin = p.splits == 1;
+  if (tsplit >= 0) {   // one K-range of a tail tile: raw sums, register order (gg_tail_fix_kernel finishes the tile)
+    float* pp = p.tail_partial + ((size_t)(L - p.tail_first) * p.tail_splits + tsplit) * (size_t)(ROWS * WC * CW);
 #pragma unroll
-  for (int t = 0; t < MT; ++t) {
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        fvec v;
+#pragma unroll
+        for (int u = 0; u < NTC; ++u) v[u] = acc[t][u][reg];
+        *reinterpret_cast<fvec*>(pp + ((size_t)(t * 16 + reg) * NT + tid) * NTC) = v;
+      }
+    return;
+  }
+  gg_epilogue<WR, WC, MT, CW, VEC>(p, acc, row_tile, col_tile, split, pncols, pGX, pdy0, pdx0);
+}
+
+// Sums the tail_splits partial tiles of one tail tile in fixed order and applies the normal epilogue.
+template <int WR, int WC, int MT, int CW, bool VEC>
+__global__ __launch_bounds__(WR* WC * 64) void gg_tail_fix_kernel(const GGParams p) {
+  constexpr int NT = WR * WC * 64, NTC = CW / 32, ROWS = WR * MT * 32;
+  using fvec = __attribute__((ext_vector_type(NTC))) float;
+  const int L = p.tail_first + blockIdx.x;
+  const int tid = threadIdx.x;
+  f32x16 acc[MT][NTC];
+  const float* pp = p.tail_partial + (size_t)blockIdx.x * p.tail_splits * (size_t)(ROWS * WC * CW);
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const int row = r0 + wr * MT * 32 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-      if (row >= p.R) continue;
-      fvec v;
+      fvec v = *reinterpret_cast<const fvec*>(pp + ((size_t)(t * 16 + reg) * NT + tid) * NTC);
+      for (int sp = 1; sp < p.tail_splits; ++sp)
+        v += *reinterpret_cast<const fvec*>(pp + (size_t)sp * (ROWS * WC * CW) + ((size_t)(t * 16 + reg) * NT + tid) * NTC);
 #pragma unroll
-      for (int u = 0; u < NTC; ++u) v[u] = acc[t][u][reg];
-      float* dp = base + (size_t)row * p.DP * N;
-      if (fin) {
-        const float bv = p.bias ? p.bias[row] : 0.f;
-        if (VEC) {
-          if (p.scaleTargets != 0.f) {
-            const fvec o = *reinterpret_cast<const fvec*>(dp);
-            v = p.scaleTargets * o + v;
-          }
-          v = v + bv;
-          if (p.relu) {
-#pragma unroll
-            for (int e = 0; e < NTC; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-          }
-          if (p.mask) {
-            const fvec mk = *reinterpret_cast<const fvec*>(p.mask + (dp - p.dst));
-#pragma unroll
-            for (int e = 0; e < NTC; ++e) v[e] = mk[e] > 0.f ? v[e] * p.post_scale : 0.f;
-          }
-          *reinterpret_cast<fvec*>(dp) = v;
-        } else {
-#pragma unroll
-          for (int e = 0; e < NTC; ++e) {
-            if (n + e < N) {
-              float x = v[e];
-              if (p.scaleTargets != 0.f) x = p.scaleTargets * dp[e] + x;
-              x += bv;
-              if (p.relu) x = x > 0.f ? x : 0.f;
-              if (p.mask) x = p.mask[(dp - p.dst) + e] > 0.f ? x * p.post_scale : 0.f;
-              dp[e] = x;
-            }
-          }
-        }
-      } else {
-        if (VEC) {
-          *reinterpret_cast<fvec*>(dp) = v;
-        } else {
-#pragma unroll
-          for (int e = 0; e < NTC; ++e)
-            if (n + e < N) dp[e] = v[e];
-        }
-      }
+      for (int u = 0; u < NTC; ++u) acc[t][u][reg] = v[u];
     }
-  }
+  gg_epilogue<WR, WC, MT, CW, VEC>(p, acc, L % p.row_tiles, L / p.row_tiles, 0, p.ncols, p.GX, p.dy0, p.dx0);
 }
 
 // dst = scaleTargets*dst + sum_s slab[s]  (+bias[row], relu) over a full dst extent.
@@ -911,7 +980,35 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   p.splits = splits;
   p.slab = dst_elems;
   p.partial = splits > 1 ? static_cast<float*>(workspace(sizeof(float) * dst_elems * splits)) : nullptr;
-  dim3 grid(((tiles + 7) / 8) * 8, splits);
+  // Tail split: more tiles than slots and a partial last round (conv2 fprop: 1352 tiles = 2.64 rounds of 512).  Cut only
+  // the last round's tiles into s K-ranges so that round is full as well: 2 + ceil(328*3/512)/3 = 2.67 rounds instead of 3.
+  p.tail_splits = 1;
+  p.tail_partial = nullptr;
+  const int slots = kTargetBlocks;
+  static const bool no_tail = getenv("CONVNET_GG_NO_TAIL_SPLIT") != nullptr;
+  if (!no_tail && splits == 1 && dst_elems > 0 && tiles > slots && tiles % slots != 0 && kchunks >= 32) {
+    const int full = (tiles / slots) * slots, rem = tiles - full;
+    const double tile_bytes = sizeof(float) * (double)ROWS * WC * CW;
+    const double t_round = 2.0 * ROWS * (WC * (double)CW) * (double)p.K / (64.0 * 4 * 2.2e9 * 0.8 / 2);   // one whole-K block
+    double best = 0.95;   // cost of the last round today = 1 round; require a 5 % gain on it
+    int best_s = 1;
+    for (int s = 2; s <= 8 && kchunks / s >= 8; ++s) {
+      const double cost = std::ceil(rem * (double)s / slots) / s + (rem * (s + 1.0) * tile_bytes / 4.0e12 + 6e-6) / t_round;
+      if (cost < best) {
+        best = cost;
+        best_s = s;
+      }
+    }
+    if (best_s > 1) {
+      p.tail_first = full;
+      p.tail_cps = divup(kchunks, best_s);
+      p.tail_splits = divup(kchunks, p.tail_cps);
+      p.tail_tf8 = full / 8;
+      p.tail_tt8 = divup(rem * p.tail_splits, 8);
+      p.tail_partial = static_cast<float*>(workspace(sizeof(float) * (size_t)rem * p.tail_splits * ROWS * WC * CW));
+    }
+  }
+  dim3 grid(p.tail_splits > 1 ? 8 * (p.tail_tf8 + p.tail_tt8) : ((tiles + 7) / 8) * 8, splits);
   dim3 block(WR * WC * 64);
   static const std::string kname = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + "," + (AK ? "kc" : "rc") + ">";
   {
@@ -923,6 +1020,12 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
       allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, false>, lds);
       hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, false>), grid, block, lds, stream(), p, kNoClasses);
     }
+  }
+  if (p.tail_splits > 1) {
+    const int rem = tiles - p.tail_first;
+    KernelTimer timer("gg_tail_fix_kernel", t_op, 0.0, sizeof(float) * (double)rem * (p.tail_splits + 1) * ROWS * WC * CW);
+    if (vec) hipLaunchKernelGGL((gg_tail_fix_kernel<WR, WC, MT, CW, true>), dim3(rem), block, 0, stream(), p);
+    else hipLaunchKernelGGL((gg_tail_fix_kernel<WR, WC, MT, CW, false>), dim3(rem), block, 0, stream(), p);
   }
   if (splits > 1) {
     KernelTimer timer("gg_reduce_kernel", t_op, 0.0, sizeof(float) * (double)dst_elems * (splits + 1));

@@ -329,3 +329,20 @@ def test_input_staging_is_bit_exact_vs_oracle_incl_ragged_sizes(hip):
                               oracle.port.div_by_col_vec(oracle.port.add_col_mult(im.copy(), mean, -1.0), std))
         got, ref = hip.normalize_columns(im.copy()), oracle.port.normalize_columns(im.copy())
         assert np.allclose(got, ref, rtol=0, atol=1e-5)      # column mean: parallel vs sequential fp32 sum
+
+
+@pytest.mark.gpu
+def test_conv_up_tail_split_more_tiles_than_slots(hip):
+    """648 block tiles on 512 resident slots: tiles 512..647 are computed as K-split pieces whose raw sums
+    gg_tail_fix_kernel adds in fixed order before the normal epilogue (accumulate / bias / ReLU).  Same result as the
+    whole-K path: CONVNET_GG_NO_TAIL_SPLIT is the A/B switch used when measuring."""
+    g = Geom(N=256, C=64, H=18, W=18, F=256, Ky=3, Kx=3, pady=1, padx=1)
+    rng = np.random.default_rng(41)
+    x, w, b = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape()), rnd(rng, (g.F,))
+    ref = oracle.port.conv_up(g, x, w)
+    assert rel_err(hip.conv_up(g, x, w), ref) < TOL
+    t0 = rnd(rng, g.out_shape())
+    assert rel_err(hip.conv_up(g, x, w, t0.copy(), 1.0), t0 + ref) < TOL
+    fused = hip.conv_up_bias_relu(g, x, w, b, relu=True)
+    y = np.maximum(ref + b.reshape(g.F, 1, 1, 1), 0.0)
+    assert rel_err(fused, y) < TOL
