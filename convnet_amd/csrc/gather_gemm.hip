@@ -463,6 +463,7 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
   // Measured on conv4 (N=256): 126 TFLOP/s with the block fetch, 121 spread, 120 spread + sched_group_barrier
   // interleave — the two resident waves of a SIMD already cover each other's staging phase, so SPREAD stays off.
   constexpr bool SPREAD = false && GLDS_A && GLDS_B;
+  constexpr bool PRIO = true;
   constexpr int NP = NA + NB, PPS = (NP + BK / 2 - 1) / (BK / 2);
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
@@ -478,6 +479,7 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
 #pragma unroll
       for (int t = 0; t < MT; ++t) a[0][t] = ar[lh * ROWS + t * 32];
       b4[0] = *reinterpret_cast<const fvec*>(bs + lh * CW);
+      if (PRIO) __builtin_amdgcn_s_setprio(2);   // MFMA phase outranks the co-resident wave's staging VALU at issue
       static_for<0, BK / 2>([&](auto KK) __attribute__((always_inline)) {
         constexpr int kk = decltype(KK)::value;
         constexpr int cur = kk & 1, nxt = cur ^ 1;
@@ -510,6 +512,7 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
           }
         }
       });
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
     } else {
       const float* ar = as + (wr * MT * 32 + li) * APITCH + 4 * lh;
 #pragma unroll
