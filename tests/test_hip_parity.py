@@ -346,3 +346,65 @@ def test_conv_up_tail_split_more_tiles_than_slots(hip):
     fused = hip.conv_up_bias_relu(g, x, w, b, relu=True)
     y = np.maximum(ref + b.reshape(g.F, 1, 1, 1), 0.0)
     assert rel_err(fused, y) < TOL
+
+
+def _random_geoms(seed, count):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        Ky, Kx = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        sy, sx = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        pady, padx = int(rng.integers(0, min(3, Ky))), int(rng.integers(0, min(3, Kx)))
+        H, W = int(rng.integers(Ky, 19)), int(rng.integers(Kx, 19))
+        N = int(rng.choice([1, 2, 3, 4, 7, 8, 12, 31, 64, 100, 129]))
+        C, F = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 33])), int(rng.choice([1, 3, 4, 16, 31, 64, 96, 100, 130]))
+        g = Geom(N=N, C=C, H=H, W=W, F=F, Ky=Ky, Kx=Kx, sy=sy, sx=sx, pady=pady, padx=padx)
+        if g.My >= 1 and g.Mx >= 1 and g.N * g.C * g.H * g.W * g.F * Ky * Kx < 4e8:
+            out.append(g)
+    return out
+
+
+@pytest.mark.gpu
+def test_conv_random_geometries_vs_oracle(hip):
+    """Seeded sweep over 48 random geometries (rectangular images / kernels / strides, paddings, every row-tile class,
+    vector and scalar paths, accumulate on and off) for fprop, dgrad, wgrad and the fused wgrad+bias."""
+    from hip_adapter import conv_outp_bias
+    rng = np.random.default_rng(77)
+    for i, g in enumerate(_random_geoms(1234, 48)):
+        x, w, dy = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape()), rnd(rng, g.out_shape())
+        st = float(i % 2)
+        t0 = rnd(rng, g.out_shape())
+        assert rel_err(hip.conv_up(g, x, w, t0.copy(), st), oracle.port.conv_up(g, x, w, t0.copy(), st)) < TOL, ("up", g)
+        t0 = rnd(rng, g.in_shape())
+        assert rel_err(hip.conv_down(g, dy, w, t0.copy(), st), oracle.port.conv_down(g, dy, w, t0.copy(), st)) < TOL, ("down", g)
+        dw0, db0 = rnd(rng, g.filt_shape()), rnd(rng, (g.F,))
+        dw, db = conv_outp_bias(g, x, dy, dw0.copy(), db0.copy(), st, 0.5 / g.N)
+        assert rel_err(dw, oracle.port.conv_outp(g, x, dy, dw0.copy(), st, 0.5 / g.N)) < TOL, ("outp", g)
+        ref_db = st * db0 + (0.5 / g.N) * dy.reshape(g.F, -1).astype(np.float64).sum(axis=1)
+        assert np.allclose(db, ref_db, rtol=3e-5, atol=2e-5 * max(1e-6, np.abs(ref_db).max())), ("db", g)
+
+
+@pytest.mark.gpu
+def test_pooling_random_square_geometries_vs_oracle(hip):
+    """Seeded sweep of square pooling set-ups (the CPU oracle only defines pool-undo for square maps / windows, SURVEY §8c
+    quirks): K 2-4, stride 1-3, padding 0..K-1, ragged and vector N — generic kernels and the fixed 3x3s2 / 2x2s2 ones."""
+    rng = np.random.default_rng(99)
+    done = 0
+    while done < 30:
+        K, s = int(rng.integers(2, 5)), int(rng.integers(1, 4))
+        pad = int(rng.integers(0, K))
+        H = int(rng.integers(K, 24))
+        N, C = int(rng.choice([1, 3, 4, 8, 20, 64, 130])), int(rng.choice([1, 2, 5, 16]))
+        g = Geom(N=N, C=C, H=H, W=H, F=C, Ky=K, Kx=K, sy=s, sx=s, pady=pad, padx=pad)
+        if g.My < 1 or (g.My - 1) * s - pad >= H:     # last window must start inside the image
+            continue
+        done += 1
+        x = np.maximum(rnd(rng, g.in_shape()), 0)
+        dy = rnd(rng, g.pooled_shape())
+        mp = hip.max_pool(g, x)
+        assert np.array_equal(mp, oracle.port.max_pool(g, x)), g
+        assert rel_err(hip.avg_pool(g, x), oracle.port.avg_pool(g, x)) < 1e-6, g
+        st = float(done % 2)
+        t0 = rnd(rng, g.in_shape())
+        assert rel_err(hip.max_pool_undo(g, x, dy, mp, t0.copy(), st), oracle.port.max_pool_undo(g, x, dy, mp, t0.copy(), st)) < 1e-6, g
+        assert rel_err(hip.avg_pool_undo(g, dy, t0.copy(), st), oracle.port.avg_pool_undo(g, dy, t0.copy(), st)) < 1e-6, g
