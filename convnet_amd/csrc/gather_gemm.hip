@@ -643,7 +643,12 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
   constexpr int FT = WN * NTL * TS;  // filters (D cols / lanes) per block
   constexpr int LH = 64 / TS;        // k-groups of a wave: lane = li + TS*lh supplies k index lh of each MFMA
   using facc = __attribute__((ext_vector_type(TS == 32 ? 16 : 4))) float;
-  constexpr int A_STAGE = KT * WG_PITCH, B_STAGE = FT * WG_PITCH;
+  // VEC: tiles are staged direct-to-LDS (global_load_lds_dwordx4), which writes lane-linear — rows of exactly 32 floats,
+  // no padding.  Bank conflicts of the row-strided ds_read_b128 fragment reads are avoided by an XOR swizzle applied at
+  // the SOURCE: LDS 16-byte slot c of row r holds images piece c ^ ((r >> 1) & 7) of that row, so the 16 lanes of a
+  // b128 access group (rows with all 16 combinations of (r & 1, (r >> 1) & 7)) hit 16 distinct 4-bank groups.
+  constexpr int PITCH = VEC ? WG_NB : WG_PITCH;
+  constexpr int A_STAGE = KT * PITCH, B_STAGE = FT * PITCH;
   constexpr int NA = (KT * 8 + NT - 1) / NT, NB = (FT * 8 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
@@ -679,7 +684,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
     a_ta[it] = tap / p.TX;
     a_tb[it] = tap - a_ta[it] * p.TX;
     a_choff[it] = ch * p.SH * p.SW;
-    a_n[it] = 4 * c4;
+    a_n[it] = 4 * (VEC ? (c4 ^ ((row >> 1) & 7)) : c4);
     a_ok[it] = ok;
     a_lds[it] = row * WG_PITCH + 4 * c4;
   }
@@ -691,7 +696,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
     const int row = idx >> 3, c4 = idx & 7;
     b_f[it] = f0 + row;
     b_ok[it] = idx < FT * 8 && b_f[it] < p.F;
-    b_n[it] = 4 * c4;
+    b_n[it] = 4 * (VEC ? (c4 ^ ((row >> 1) & 7)) : c4);
     b_lds[it] = row * WG_PITCH + 4 * c4;
   }
 
@@ -715,7 +720,10 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
 #pragma unroll
     for (int it = 0; it < NB; ++it) b_const[it] = (unsigned)(b_ok[it] ? b_f[it] : 0) * (unsigned)p.M * (unsigned)N + (unsigned)b_n[it];
   }
-  auto fetch_vec = [&]() {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto fetch_vec = [&](int buf) {
     const int ysb = w_oy * p.ssy + p.y0, xsb = w_ox * p.ssx + p.x0;
     const int nb = w_nc * WG_NB;
     const unsigned ua = (unsigned)(ysb * p.SW + xsb) * (unsigned)N + (unsigned)nb;
@@ -723,12 +731,16 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const bool ok = a_ok[it] && (unsigned)(ysb + a_ta[it]) < (unsigned)p.SH && (unsigned)(xsb + a_tb[it]) < (unsigned)p.SW && nb + a_n[it] < N;
-      ra[it] = ld4(ok ? p.src + (a_const[it] + ua) : p.zero + a_alt[it]);
+      const float* src = ok ? p.src + (a_const[it] + ua) : p.zero + a_alt[it];
+      if (tid + it * NT < KT * 8)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(As + buf * A_STAGE + 4 * (64 * wave_u + it * NT)), 16, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
       const bool ok = b_ok[it] && nb + b_n[it] < N;
-      rb[it] = ld4(ok ? p.dout + (b_const[it] + ub) : p.zero);
+      const float* src = ok ? p.dout + (b_const[it] + ub) : p.zero;
+      if (tid + it * NT < FT * 8)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(Bs + buf * B_STAGE + 4 * (64 * wave_u + it * NT)), 16, 0, 0);
     }
     if (++w_nc == p.nchunk) {
       w_nc = 0;
@@ -740,9 +752,9 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
     }
   };
 
-  auto fetch = [&](int c) {
+  auto fetch = [&](int c, int buf) {
     if (VEC) {
-      fetch_vec();   // stateful: called for c = cbeg, cbeg+1, ... in order
+      fetch_vec(buf);   // stateful: called for c = cbeg, cbeg+1, ... in order; lands in LDS stage `buf` directly
       return;
     }
     const int m = c / p.nchunk, nc = c - m * p.nchunk;
@@ -786,6 +798,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
     }
   };
   auto stash = [&](int buf) {
+    if (VEC) return;   // already in LDS
     float* as = As + buf * A_STAGE;
     float* bs = Bs + buf * B_STAGE;
 #pragma unroll
@@ -805,22 +818,24 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
       for (int e = 0; e < (TS == 32 ? 16 : 4); ++e) acc[t][u][e] = 0.f;
 
   if (cend > cbeg) {
-    fetch(cbeg);
+    fetch(cbeg, 0);
     stash(0);
   }
   __syncthreads();
+  const int swz = VEC ? ((li >> 1) & 7) : 0;   // (row >> 1) & 7 of every fragment row this lane reads (tile bases are multiples of 16)
   for (int c = cbeg; c < cend; ++c) {
     const int buf = (c - cbeg) & 1;
-    if (c + 1 < cend) fetch(c + 1);
-    const float* ar = As + buf * A_STAGE + (wm * MT * TS + li) * WG_PITCH + 4 * lh;
-    const float* br = Bs + buf * B_STAGE + (wn * NTL * TS + li) * WG_PITCH + 4 * lh;
+    if (c + 1 < cend) fetch(c + 1, buf ^ 1);
+    const float* ar = As + buf * A_STAGE + (wm * MT * TS + li) * PITCH;
+    const float* br = Bs + buf * B_STAGE + (wn * NTL * TS + li) * PITCH;
 #pragma unroll
     for (int q = 0; q < WG_NB / (4 * LH); ++q) {   // one b128 per lane = 4*LH images of the stage
+      const int piece = 4 * ((LH * q + lh) ^ swz);
       f32x4 a4[MT], b4[NTL];
 #pragma unroll
-      for (int t = 0; t < MT; ++t) a4[t] = ld4(ar + t * TS * WG_PITCH + 4 * LH * q);
+      for (int t = 0; t < MT; ++t) a4[t] = ld4(ar + t * TS * PITCH + piece);
 #pragma unroll
-      for (int u = 0; u < NTL; ++u) b4[u] = ld4(br + u * TS * WG_PITCH + 4 * LH * q);
+      for (int u = 0; u < NTL; ++u) b4[u] = ld4(br + u * TS * PITCH + piece);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -1072,7 +1087,7 @@ void gg_run_classes(GGParams& p, GGClassTable& ct, bool vec) {   // same tile ch
 template <int WM, int WN, int MT, int NTL, int TS = 32>
 void wg_launch_cfg(WGParams& p, bool vec) {
   constexpr int KT = WM * MT * TS, FT = WN * NTL * TS;
-  const size_t lds = sizeof(float) * 2 * (KT + FT) * WG_PITCH;
+  const size_t lds = sizeof(float) * 2 * (KT + FT) * (vec ? WG_NB : WG_PITCH);
   p.k_tiles = divup(p.K, KT);
   if (p.bias_dst && divup(p.K + 1, KT) != p.k_tiles) p.bias_dst = nullptr;   // no padding row to spare: caller sums separately
   p.f_tiles = divup(p.F, FT);
