@@ -180,8 +180,11 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT]
 
 // CW = images per wave-column (128: 4 interleaved 32-image MFMA column tiles per wave, ds_read_b128;
 // 64: 2 tiles, ds_read_b64 — used with MT=3 so a 96-row problem (conv1 fprop, conv2 dgrad) fills its tile).
-template <int WR, int WC, int MT, int CW, bool A_KCONTIG, bool VEC>
-__global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg_kernel(const GGParams pin, const GGClassTable ct) {
+// O3 = the 3-blocks-per-CU build (launch bound 3 waves/SIMD + the k-row-major B stage that makes it fit): chosen by the
+// host only for launches with enough tiles to fill >= 2 rounds of 768 slots, where it gains 2-6 %; on ~512-tile launches
+// the blocks spread 3/1 over the CUs and it loses, so the 2-block build stays the default.
+template <int WR, int WC, int MT, int CW, bool A_KCONTIG, bool VEC, bool O3 = false>
+__global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGParams pin, const GGClassTable ct) {
   constexpr int NT = WR * WC * 64;
   constexpr int NTC = CW / 32, CW4 = CW / 4;
   using fvec = __attribute__((ext_vector_type(NTC))) float;
@@ -238,12 +241,23 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
   const int N = p.N;
 
   // ---- per-thread constants for the B (source) staging slots -----------------------------------
+  // VEC (direct-to-LDS) lays the B stage out k-row major, [krow][wave-column][image]: one wave instruction (64 lanes x
+  // 16 B) then fills exactly one k-row (or half of one), so the k-row — and with it the whole (channel, tap_y, tap_x)
+  // decode — is WAVE-UNIFORM and lives in SGPRs/SALU, while a lane's (wave-column, image quad) is the same for all of
+  // its slots.  That removes ~28 VGPRs of per-slot state and most of the staging VALU work.  The scalar path keeps the
+  // [wave-column][krow][image] layout.
+  constexpr bool KM = O3;
+  static_assert(!O3 || VEC, "the 3-block build is a vector-path variant");
+  constexpr int KROW_LANES = WC * CW4;   // lanes (16-B pieces) per k-row: 64 or 128
+  static_assert(!KM || (NT % KROW_LANES == 0 && (KROW_LANES == 64 || KROW_LANES == 128)), "k-row must align with wave instructions");
+  constexpr int BROW = KM ? WC * CW : CW;   // floats between consecutive k-rows of one wave-column in LDS
   int b_ys0[NB], b_xs0[NB], b_n[NB], b_lds[NB], b_krow[NB];
   bool b_ok[NB];
 #pragma unroll
   for (int it = 0; it < NB; ++it) {
     const int idx = tid + it * NT;
-    const int wcol = idx / (BK * CW4), krow = (idx / CW4) % BK, c4 = idx % CW4;
+    const int sub = tid % KROW_LANES;   // KM: the same for every slot of this lane
+    const int wcol = KM ? sub / CW4 : idx / (BK * CW4), krow = KM ? 0 : (idx / CW4) % BK, c4 = KM ? sub % CW4 : idx % CW4;
     const int colid = col_tile * WC + wcol;
     const bool ok = idx < WC * BK * CW4 && colid < pncols;
     const int m = ok ? colid / p.nblk : 0, blk = ok ? colid % p.nblk : 0;
@@ -279,7 +293,8 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
   if (VEC) {
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
-      const int k = kbeg + b_krow[it];
+      const int k = kbeg + (KM ? (64 * __builtin_amdgcn_readfirstlane(tid >> 6) + it * NT) / KROW_LANES   // wave-uniform k-row
+                               : b_krow[it]);
       const int ch = k / pTYX, tap = k - ch * pTYX;
       s_k[it] = k;
       s_ch[it] = ch;
@@ -293,9 +308,12 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
       if (!A_KCONTIG) {
         const int krow = idx / (ROWS / 4), c4 = idx % (ROWS / 4);
         const int r = r0 + 4 * c4;
-        a_k[it] = kbeg + krow;
+        // the pointer is the whole slot state: rows past R (or lanes past the tile) start AT the end sentinel and only
+        // move further, in-range rows cross it exactly when their k reaches kend (see fetch_a_piece)
+        // (3-block build only: saves the k counter and the in-range flag; the 64-bit compare costs the 2-block build 1 %)
+        a_k[it] = O3 ? 0 : kbeg + krow;
         a_ok[it] = idx < BK * (ROWS / 4) && r < p.R;
-        a_ptr[it] = pA + (size_t)p.lda * a_k[it] + r;
+        a_ptr[it] = (a_ok[it] || !O3) ? pA + (size_t)p.lda * (kbeg + krow) + r : pA + (size_t)p.lda * kend + p.R;
       } else {
         const int row = idx / (BK / 4), c4 = idx % (BK / 4);
         const int r = r0 + row;
@@ -320,10 +338,11 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
   const float* const q_zero = p.zero;
   const float* const q_src = p.src;
   const int q_lda = p.lda, q_dir = p.dir, q_SH = p.SH, q_SW = p.SW;
+  const float* const a_end = pA + (size_t)p.lda * kend;   // r-contiguous A: first address of row k = kend
   auto fetch_a_piece = [&](auto IT, int buf) __attribute__((always_inline)) {
     constexpr int it = decltype(IT)::value;
-    const bool ok = a_ok[it] && a_k[it] < kend;
     const float* const ap = a_ptr[it];   // rvalues: a conditional on two lvalues selects an ADDRESS and keeps both in memory
+    const bool ok = (A_KCONTIG || !O3) ? (a_ok[it] && a_k[it] < kend) : ap < a_end;
     const float* src = ok ? ap + 0 : q_zero + 0;
     if (GLDS_A) {
       if (tid + it * NT < BK * (ROWS / 4))
@@ -336,9 +355,11 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
   };
   auto fetch_b_piece = [&](auto IT, int buf) __attribute__((always_inline)) {
     constexpr int it = decltype(IT)::value;
-    const int ys = b_ys0[it] + q_dir * s_a[it], xs = b_xs0[it] + q_dir * s_b[it];
-    const bool ok = b_ok[it] && s_k[it] < kend && (unsigned)ys < (unsigned)q_SH && (unsigned)xs < (unsigned)q_SW;
-    const unsigned off = (unsigned)((s_ch[it] * q_SH + ys) * q_SW + xs) * (unsigned)N + (unsigned)b_n[it];
+    // lane constants are slot-independent in the k-row-major layout (slot 0 holds them); s_* are wave-uniform
+    constexpr int lc = KM ? 0 : it;
+    const int ys = b_ys0[lc] + q_dir * s_a[it], xs = b_xs0[lc] + q_dir * s_b[it];
+    const bool ok = b_ok[lc] && s_k[it] < kend && (unsigned)ys < (unsigned)q_SH && (unsigned)xs < (unsigned)q_SW;
+    const unsigned off = (unsigned)((s_ch[it] * q_SH + ys) * q_SW + xs) * (unsigned)N + (unsigned)b_n[lc];
     const float* src = ok ? q_src + off : q_zero;
     if (GLDS_B) {
       if (tid + it * NT < WC * BK * CW4)
@@ -470,7 +491,7 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
     const bool more = c + 1 < nchunks;
     if (!SPREAD && more) fetch(kbeg + (c + 1) * BK, buf ^ 1);
     const float* as = As + buf * A_STAGE;
-    const float* bs = Bs + buf * B_STAGE + wc * BK * CW + NTC * li;
+    const float* bs = Bs + buf * B_STAGE + (KM ? wc * CW : wc * BK * CW) + NTC * li;
     if (!A_KCONTIG) {
       const float* ar = as + wr * MT * 32 + li;
       // fragments for step kk+1 are requested before the MFMAs of step kk
@@ -478,7 +499,7 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
       fvec b4[2];
 #pragma unroll
       for (int t = 0; t < MT; ++t) a[0][t] = ar[lh * ROWS + t * 32];
-      b4[0] = *reinterpret_cast<const fvec*>(bs + lh * CW);
+      b4[0] = *reinterpret_cast<const fvec*>(bs + lh * BROW);
       if (PRIO) __builtin_amdgcn_s_setprio(2);   // MFMA phase outranks the co-resident wave's staging VALU at issue
       static_for<0, BK / 2>([&](auto KK) __attribute__((always_inline)) {
         constexpr int kk = decltype(KK)::value;
@@ -487,7 +508,7 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
           const int krow = 2 * (kk + 1) + lh;
 #pragma unroll
           for (int t = 0; t < MT; ++t) a[nxt][t] = ar[krow * ROWS + t * 32];
-          b4[nxt] = *reinterpret_cast<const fvec*>(bs + krow * CW);
+          b4[nxt] = *reinterpret_cast<const fvec*>(bs + krow * BROW);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (SPREAD && more) {
@@ -522,7 +543,7 @@ __global__ __launch_bounds__(WR* WC * 64, (WR * WC * 64 <= 256 ? 2 : 1)) void gg
         for (int t = 0; t < MT; ++t) a4[t] = ld4(ar + t * 32 * APITCH + 8 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const fvec b4 = *reinterpret_cast<const fvec*>(bs + (8 * q + 4 * lh + e) * CW);
+          const fvec b4 = *reinterpret_cast<const fvec*>(bs + (8 * q + 4 * lh + e) * BROW);
 #pragma unroll
           for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -973,6 +994,11 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   p.zero = zero_page();
   const int tiles = p.row_tiles * p.col_tiles;
   const int kchunks = divup(p.K, BK);
+  // 3 blocks per CU (768 slots) for launches with at least two such rounds of tiles; only the 128-row r-contiguous
+  // vector build has the variant (it is the one whose register count sits between the 2- and 3-block limits).
+  static const bool no_o3 = getenv("CONVNET_GG_NO_O3") != nullptr;
+  const bool o3 = !no_o3 && vec && !AK && WR == 2 && WC == 2 && MT == 2 && CW == 128 && tiles >= 2 * 768;
+  const int slots_launch = o3 ? 768 : kTargetBlocks;
   // Split-K factor by wave quantisation: every block of a launch takes the same time, so a grid of b
   // blocks on `slots` resident-block slots runs ceil(b/slots) rounds and wastes the empty part of the
   // last one (338 tiles on 512 slots = 66 % busy; 3 K-splits = 1014 blocks = 99 %).  Pick the split with
@@ -980,7 +1006,7 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   // the whole destination (dst_elems > 0).
   int splits = 1;
   if (dst_elems > 0 && kchunks >= 16) {
-    const double slots = kTargetBlocks;
+    const double slots = slots_launch;
     const double flops = 2.0 * ROWS * (WC * (double)CW) * (double)p.K;           // per tile, all K
     double best_t = 1e30;
     for (int sp = 1; sp <= 16 && kchunks / sp >= 8; ++sp) {
@@ -1002,7 +1028,7 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   // the last round's tiles into s K-ranges so that round is full as well: 2 + ceil(328*3/512)/3 = 2.67 rounds instead of 3.
   p.tail_splits = 1;
   p.tail_partial = nullptr;
-  const int slots = kTargetBlocks;
+  const int slots = slots_launch;
   static const bool no_tail = getenv("CONVNET_GG_NO_TAIL_SPLIT") != nullptr;
   if (!no_tail && splits == 1 && dst_elems > 0 && tiles > slots && tiles % slots != 0 && kchunks >= 32) {
     const int full = (tiles / slots) * slots, rem = tiles - full;
@@ -1031,7 +1057,14 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   static const std::string kname = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + "," + (AK ? "kc" : "rc") + ">";
   {
     KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0);
-    if (vec) {
+    if constexpr (!AK && WR == 2 && WC == 2 && MT == 2 && CW == 128) {
+      if (o3) {
+        allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, true, true>, lds);
+        hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, true, true>), grid, block, lds, stream(), p, kNoClasses);
+      }
+    }
+    if (o3) {
+    } else if (vec) {
       allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, true>, lds);
       hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, true>), grid, block, lds, stream(), p, kNoClasses);
     } else {

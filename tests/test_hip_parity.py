@@ -408,3 +408,17 @@ def test_pooling_random_square_geometries_vs_oracle(hip):
         t0 = rnd(rng, g.in_shape())
         assert rel_err(hip.max_pool_undo(g, x, dy, mp, t0.copy(), st), oracle.port.max_pool_undo(g, x, dy, mp, t0.copy(), st)) < 1e-6, g
         assert rel_err(hip.avg_pool_undo(g, dy, t0.copy(), st), oracle.port.avg_pool_undo(g, dy, t0.copy(), st)) < 1e-6, g
+
+
+@pytest.mark.gpu
+def test_conv_up_three_blocks_per_cu_build(hip):
+    """1600 block tiles (>= 2 rounds of 768 slots) selects the 3-blocks-per-CU build of gg_kernel (k-row-major B stage,
+    wave-uniform tap decode); 1600 = 2 x 768 + 64 also leaves a tail that is K-split.  Padding, accumulate, bias + ReLU."""
+    g = Geom(N=256, C=36, H=40, W=40, F=128, Ky=3, Kx=3, pady=1, padx=1)
+    rng = np.random.default_rng(43)
+    x, w, b = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape()), rnd(rng, (g.F,))
+    ref = oracle.port.conv_up(g, x, w)
+    assert rel_err(hip.conv_up(g, x, w), ref) < TOL
+    t0 = rnd(rng, g.out_shape())
+    assert rel_err(hip.conv_up(g, x, w, t0.copy(), 1.0), t0 + ref) < TOL
+    assert rel_err(hip.conv_up_bias_relu(g, x, w, b, relu=True), np.maximum(ref + b.reshape(g.F, 1, 1, 1), 0.0)) < TOL
