@@ -91,6 +91,7 @@ def _load():
         sig(ev_fn, I, P(ctypes.c_void_p))
     sig("cublas_init", I)
     sig("cublas_shutdown", I)
+    sig("destroy_tex", I, M)
     sig("convnet_hip_last_kernel_info", None, P(KernelInfo))
     sig("convnet_hip_profile_enable", None, I)
     sig("convnet_hip_profile_report", ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t)

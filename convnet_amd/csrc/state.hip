@@ -159,6 +159,12 @@ static int event_status(hipError_t err) {
 int cuda_create_event(void** t) { return event_status(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(t), hipEventDisableTiming)); }
 int cuda_record_event(void** t) { return event_status(hipEventRecord(*reinterpret_cast<hipEvent_t*>(t), g_stream)); }
 int cuda_synchronize_event(void** t) { return event_status(hipStreamWaitEvent(g_stream, *reinterpret_cast<hipEvent_t*>(t), 0)); }
+// The reference's Matrix destructor releases the texture view of every matrix (src/matrix.cc:~Matrix -> cudamat.cu destroy_tex);
+// this library never binds textures (tex_obj stays 0), so there is nothing to release.
+int destroy_tex(cudamat* mat) {
+  if (mat) mat->tex_obj = 0;
+  return 0;
+}
 int cublas_init(void) { return 0; }
 int cublas_shutdown(void) {
   convnet_hip_shutdown();
@@ -245,8 +251,13 @@ int copy_to_host_slice(cudamat* mat, size_t start, size_t end) {
 }
 
 int copy_to_device_slice(cudamat* mat, size_t start, size_t end) {
-  if (!mat->on_device) return ERROR_NOT_ON_DEVICE;
-  if (end > (size_t)mat->size[1] || start > end) return ERROR_INCOMPATIBLE_DIMENSIONS;
+  // cudamat.cu:325-347: ERROR_GENERIC for an empty / out-of-range slice, and — like copy_to_device — the first copy of a
+  // host-only matrix allocates its device memory (the reference's Matrix::AllocateGPUMemory relies on it, matrix.cc:105-106)
+  if (end <= start || end > (size_t)mat->size[1]) return ERROR_GENERIC;
+  if (!mat->on_device) {
+    const int rc = allocate_device_memory(mat);
+    if (rc) return rc;
+  }
   const size_t off = start * mat->size[0], bytes = (end - start) * mat->size[0] * sizeof(float);
   if (hipMemcpyAsync(mat->data_device + off, mat->data_host + off, bytes, hipMemcpyHostToDevice, g_stream) != hipSuccess) return CUDA_ERROR;
   return hipStreamSynchronize(g_stream) == hipSuccess ? 0 : CUDA_ERROR;

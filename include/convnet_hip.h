@@ -97,6 +97,7 @@ int cuda_record_event(void** t);
 int cuda_synchronize_event(void** t);
 int cublas_init(void);                               /* cudamat.cuh:93 — no BLAS handle here: returns 0 */
 int cublas_shutdown(void);                           /* cudamat.cuh:94 — frees the scratch arenas */
+int destroy_tex(cudamat* mat);                       /* cudamat.cuh:127 — called by the reference's Matrix destructor; no textures here */
 
 /* ---- memory / views (cudamat.cuh:124-153) -------------------------------------------------------- */
 int allocate_device_memory(cudamat* mat);
