@@ -142,4 +142,32 @@ void seam_misc(int op, float* m, int rows, int cols, float* v, float alpha, floa
   else { load(V, v, rows, cols); M.ApplyDerivativeOfReLU(V); store(M, m); }
 }
 
+// Output layer + optimizer pieces exactly as SoftmaxLayer / CrossEntropyMultinomial / SGDOptimizer call them (layer.cc:570,
+// loss_functions.cc:81-120, optimizer.cc:174-200).  probs (N, classes) holds logits on entry; labels (N, 1).
+// out_deriv (N, classes), out_correct / out_ce (N, 1).
+void seam_softmax(float* probs, const float* labels, float* out_deriv, float* out_correct, float* out_ce, int N, int classes) {
+  Matrix state, gt, deriv, correct, ce;
+  load(state, probs, N, classes); load(gt, labels, N, 1); load(deriv, out_deriv, N, classes); load(correct, out_correct, N, 1);
+  load(ce, out_ce, N, 1);
+  state.ApplySoftmax();
+  Matrix::SoftmaxCEDeriv(state, gt, deriv);
+  Matrix::SoftmaxCorrect(state, gt, correct);
+  Matrix::SoftmaxCE(state, gt, ce);
+  store(state, probs); store(deriv, out_deriv); store(correct, out_correct); store(ce, out_ce);
+}
+
+// One SGD step on a (rows, cols) tensor with the reference's Matrix-call sequence (optimizer.cc:174-200), then the row-norm limit.
+void seam_sgd(float* grad, float* param, float* hist, int rows, int cols, float l2, float clip, float eps, float mom, float norm_limit) {
+  Matrix g, w, h;
+  load(g, grad, rows, cols); load(w, param, rows, cols); load(h, hist, rows, cols);
+  if (l2 > 0) g.Add(w, l2);
+  if (clip > 0) g.UpperBoundMod(clip);
+  g.Mult(eps);
+  h.Mult(mom);
+  h.Add(g);
+  w.Add(h, -1);
+  if (norm_limit > 0) w.NormLimitByAxis(1, norm_limit, false);
+  store(g, grad); store(w, param); store(h, hist);
+}
+
 }  // extern "C"

@@ -127,3 +127,36 @@ def test_reference_matrix_rnorm_dot_and_layer_helpers_run_on_this_library(seam):
     ref = oracle.port.relu_deriv(deriv.copy(), m)
     seam.seam_misc(I(3), _p(deriv), I(N), I(Fo), _p(m), F(0), F(0))
     assert np.array_equal(deriv, ref)
+
+
+def test_reference_matrix_output_layer_and_sgd_sequence_run_on_this_library(seam):
+    """SoftmaxLayer::ApplyActivation + CrossEntropyMultinomial (deriv, correct count, CE) and the SGDOptimizer::Optimize call
+    sequence (AddMult l2, UpperBoundMod clip, Mult eps, history update, parameter update, NormLimitByAxis) issued by the
+    reference's Matrix methods: softmax to 1e-5, the SGD step to an ulp against the oracle."""
+    rng = np.random.default_rng(8)
+    N, classes = 37, 10
+    logits = (3 * rnd(rng, (classes, N))).astype(np.float32)
+    labels = rng.integers(0, classes, N).astype(np.float32)
+    probs = logits.copy()
+    deriv, correct, ce = np.zeros((classes, N), np.float32), np.zeros(N, np.float32), np.zeros(N, np.float32)
+    seam.seam_softmax(_p(probs), _p(labels), _p(deriv), _p(correct), _p(ce), I(N), I(classes))
+    p_ref = oracle.port.softmax_row_major(logits.copy())
+    assert np.allclose(probs, p_ref, rtol=1e-5, atol=1e-7)
+    assert np.allclose(deriv, oracle.port.softmax_grad_row_major(p_ref.copy(), labels), rtol=1e-5, atol=1e-6)
+    assert np.array_equal(correct, np.asarray(oracle.port.softmax_correct_row_major(p_ref, labels)).reshape(-1))
+    assert np.allclose(ce, np.asarray(oracle.port.softmax_ce_row_major(p_ref, labels)).reshape(-1), rtol=1e-5, atol=1e-6)
+    rows, cols = 30, 12
+    g0, w0, h0 = rnd(rng, (cols, rows)), rnd(rng, (cols, rows)), rnd(rng, (cols, rows))
+    g, w, h = g0.copy(), w0.copy(), h0.copy()
+    seam.seam_sgd(_p(g), _p(w), _p(h), I(rows), I(cols), F(5e-4), F(0.9), F(0.01), F(0.7), F(0.0))
+    gr, wr, hr = g0.copy(), w0.copy(), h0.copy()
+    oracle.port.sgd_step(gr, wr, hr, 5e-4, 0.9, 0.01, 0.7, 0.0, 0.0)
+    # the unfused Matrix calls are single fp32 ops each; add_mult (g += l2*w) contracts to an fma on the GPU (as cublasSaxpy does
+    # on the reference's own GPU path), so this sequence agrees with the CPU oracle to an ulp, not bit for bit — the
+    # bit-exact guarantee is the fused sgd_momentum_step entry (tests/test_hip_parity.py)
+    assert np.allclose(g, gr, rtol=3e-7, atol=1e-9) and np.allclose(h, hr, rtol=3e-7, atol=1e-9) and np.allclose(w, wr, rtol=3e-7, atol=1e-9)
+    g, w, h = g0.copy(), (3 * w0).copy(), h0.copy()
+    seam.seam_sgd(_p(g), _p(w), _p(h), I(rows), I(cols), F(0.0), F(0.0), F(0.01), F(0.5), F(2.0))
+    gr, wr, hr = g0.copy(), (3 * w0).copy(), h0.copy()
+    oracle.port.sgd_step(gr, wr, hr, 0.0, 0.0, 0.01, 0.5, 2.0, 0.0)
+    assert np.allclose(w, wr, rtol=2e-6, atol=1e-7) and np.abs(np.linalg.norm(w.reshape(cols, rows), axis=0)).max() <= 2.0 * (1 + 1e-5)
