@@ -181,12 +181,14 @@ def vgg(image_size=224, num_classes=1000, widths=(64, 128, 256, 512, 512), depth
 def count_macs(net):
     """(fwd_macs, train_macs) per image following BASELINE.md §2: train = fwd + wgrad (all weighted
     edges) + dgrad (all but edges whose source is an input layer, src/convnet.cc:370)."""
-    from .edge import ConvEdge, FCEdge
+    from .edge import ConvEdge, ConvOneToOneEdge, FCEdge
     fwd = train = 0
     for e in net.edges_:
         if isinstance(e, ConvEdge):
             d = e.conv_desc_
             macs = e.num_modules_y_ * e.num_modules_x_ * d.num_output_channels * d.kernel_size_y * d.kernel_size_x * d.num_input_channels
+        elif isinstance(e, ConvOneToOneEdge):     # 1x1 conv: C x F per pixel
+            macs = e.num_modules_y_ * e.num_modules_x_ * e.num_input_channels_ * e.num_output_channels_
         elif isinstance(e, FCEdge):
             macs = e._input_size() * e.num_output_channels_
         else:

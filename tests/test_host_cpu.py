@@ -154,3 +154,16 @@ def test_committed_bench_line_follows_the_driver_contract():
     assert r["achieved"] == pytest.approx(r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12, rel=2e-2)
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == "images/sec" and c["sample"]
+
+
+def test_nin_model_graph_and_work_count():
+    """CLS_net_20140801232522 (CONV_ONETOONE layers): layer sizes, parameter count of a 1x1 edge and MACs per image with the
+    1x1 convolutions counted per pixel."""
+    net = ConvNet(models.alexnet_nin())
+    sizes = {l.GetName(): (l.GetSizeY(), l.GetNumChannels()) for l in net.layers_}
+    assert sizes["hidden2_conv"] == (27, 256) and sizes["hidden2_conv_nin1"] == (27, 256) and sizes["hidden2_maxpool"] == (14, 256)
+    assert sizes["hidden4_conv_nin1"] == (14, 768) and sizes["hidden5_conv_nin2"] == (12, 512) and sizes["hidden5_maxpool"] == (6, 512)
+    e = net.GetEdgeByName("hidden3_conv:hidden3_conv_nin1")
+    assert e.GetParameterMemoryRequirement() == 768 * (384 + 1)
+    fwd, train = models.count_macs(net)
+    assert fwd == 2035639424 and train == 5936163072
