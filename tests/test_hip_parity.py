@@ -422,3 +422,25 @@ def test_conv_up_three_blocks_per_cu_build(hip):
     t0 = rnd(rng, g.out_shape())
     assert rel_err(hip.conv_up(g, x, w, t0.copy(), 1.0), t0 + ref) < TOL
     assert rel_err(hip.conv_up_bias_relu(g, x, w, b, relu=True), np.maximum(ref + b.reshape(g.F, 1, 1, 1), 0.0)) < TOL
+
+
+@pytest.mark.gpu
+def test_conv_down_mask_with_tail_split(hip):
+    """Stride-1 dgrad with the fused ReLU' + dropout' epilogue (convDownMask) at 648 tiles: whole-K blocks and K-split tail
+    tiles must apply accumulate -> mask -> post-scale identically."""
+    from convnet_amd.matrix import Matrix
+    from hip_adapter import _desc, _mat
+    g = Geom(N=256, C=256, H=18, W=18, F=64, Ky=3, Kx=3, pady=1, padx=1)
+    rng = np.random.default_rng(47)
+    dy, w = rnd(rng, g.out_shape()), rnd(rng, g.filt_shape())
+    state = np.maximum(rnd(rng, g.in_shape()), 0)          # the source layer's post-ReLU state: ~half zeros
+    ref = oracle.port.conv_down(g, dy, w)
+    for st in (0.0, 1.0):
+        t0 = rnd(rng, g.in_shape())
+        D = hip._act(dy, g.N, g.Mx, g.My, g.F)
+        W = _mat(w, g.F, g.K, (g.F, g.Kx, g.Ky, g.C))
+        S = hip._act(state, g.N, g.W, g.H, g.C)
+        T = hip._act(t0, g.N, g.W, g.H, g.C)
+        Matrix.ConvDownMask(D, W, S, T, _desc(g), st, 1.25)
+        want = np.where(state > 0, (st * t0 + ref) * 1.25, 0.0).astype(np.float32)
+        assert rel_err(T.ToNumpy().reshape(g.in_shape()), want) < TOL
