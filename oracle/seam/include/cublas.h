@@ -3,6 +3,7 @@
  * library.  It supplies exactly the four CUDA names those files mention outside the cudamat ABI
  * (cudamat.cuh:36,110-112; matrix.h:226; matrix.cc:536-537).  Not used by the product. */
 #pragma once
+#include <stddef.h>
 typedef void* cudaEvent_t;                       /* matrix.h:226 `cudaEvent_t ready_` — opaque handle, as hipEvent_t is */
 typedef unsigned long long cudaTextureObject_t;  /* cudamat.cuh:36 — the opaque 64-bit slot of struct cudamat */
 typedef int cudaError_t;

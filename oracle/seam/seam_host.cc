@@ -1,0 +1,254 @@
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+//
+// The reference's WHOLE HOST — src/convnet.cc, grad_check.cc, layer.cc, loss_functions.cc, optimizer.cc, edge.cc,
+// edge_with_weight.cc and every *_edge.cc — compiled UNMODIFIED from where it lies under /root/reference and linked either to
+//   (hip) the reference's GPU `class Matrix` (src/matrix.cc, unmodified) over THIS repo's libconvnet_hip.so, or
+//   (cpu) the reference's CPU `class Matrix` (src/CPUMatrix.cc + eigenmat) — the oracle.
+// So `ConvNet::Train` / `GradChecker::Run` of the reference run on the MI355X with no source change, and the same driver on
+// the reference's CPU path gives the numbers to compare with.  Stand-ins (oracle/seam/): a generated config header instead of
+// protoc's (gen_config_pb.py, from the reference's .proto), <cublas.h>, <CImg/CImg.h>, <google/protobuf/text_format.h>, and
+// datahandler.h / datawriter.h replaced by a synthetic in-memory DataHandler (seam_datahandler.h).  This file supplies what
+// src/util.cc would have (util.cc needs protobuf + CImg): the pbtxt reader over the generated classes, the HDF5 helpers (real,
+// over libhdf5, as util.cc:128-208), and no-op display hooks; plus extern "C" trampolines for tests/test_reference_host.py.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+#include <new>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "convnet.h"
+#include "edge_with_weight.h"
+#include "grad_check.h"
+#ifdef USE_CUDA
+#include "seam_pools.h"
+#endif
+
+using std::string;
+using std::vector;
+
+// ---- src/util.h functions ------------------------------------------------------------------------------------------
+template <class T>
+void ReadPbtxt(const string& pbtxt_file, T& model) {
+  std::ifstream f(pbtxt_file.c_str());
+  if (!f) {
+    std::cerr << "Could not open " << pbtxt_file << std::endl;
+    exit(1);
+  }
+  std::stringstream ss;
+  ss << f.rdbuf();
+  model.ParseFromText(ss.str());
+}
+template <class T>
+void WritePbtxt(const string&, const T&) {}
+template void ReadPbtxt<config::Model>(const string&, config::Model&);
+template void ReadPbtxt<config::DatasetConfig>(const string&, config::DatasetConfig&);
+template void ReadPbtxt<config::FeatureExtractorConfig>(const string&, config::FeatureExtractorConfig&);
+template void WritePbtxt<config::Model>(const string&, const config::Model&);
+
+string GetStringError(int err_code) {
+  char buf[64];
+  snprintf(buf, sizeof buf, "cudamat error %d", err_code);
+  return string(buf);
+}
+
+#ifndef USE_CUDA
+// The reference's GPU Matrix allocates host memory with calloc (src/matrix.cc:146) and its optimizers rely on that: the momentum
+// history is never cleared (src/optimizer.cc:135).  The CPU Matrix uses `new float[]` (src/CPUMatrix.cc:120), i.e. reads
+// uninitialised memory on the first update.  Give the CPU build the same zeroed allocations (library-local: -Bsymbolic).
+void* operator new[](size_t n) {
+  void* p = calloc(n ? n : 1, 1);
+  if (!p) throw std::bad_alloc();
+  return p;
+}
+void operator delete[](void* p) noexcept { free(p); }
+#endif
+
+#ifdef USE_CUDA
+// src/matrix.cc:1152 asks the CUDA runtime which device is current; on this platform that is the HIP runtime
+extern "C" int hipGetDevice(int* dev);
+extern "C" cudaError_t cudaGetDevice(int* dev) { return hipGetDevice(dev); }
+#endif
+
+void AddVectors(vector<float>& a, vector<float>& b) {
+  if (a.size() == 0) a.resize(b.size(), 0.f);
+  for (size_t i = 0; i < a.size() && i < b.size(); ++i) a[i] += b[i];
+}
+string GetTimeStamp() { return "seam"; }
+bool ReadLines(const string& filename, vector<string>& lines) {
+  std::ifstream f(filename.c_str());
+  if (!f) return false;
+  string line;
+  while (std::getline(f, line)) lines.push_back(line);
+  return true;
+}
+
+void WriteHDF5CPU(hid_t file, float* mat, int rows, int cols, const string& name) {
+  hsize_t dimsf[2] = {(hsize_t)rows, (hsize_t)cols};
+  hid_t space = H5Screate_simple(2, dimsf, NULL);
+  hid_t ds = H5Dcreate2(file, name.c_str(), H5T_NATIVE_FLOAT, space, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+  H5Dwrite(ds, H5T_NATIVE_FLOAT, H5S_ALL, H5S_ALL, H5P_DEFAULT, mat);
+  H5Sclose(space);
+  H5Dclose(ds);
+}
+void WriteHDF5CPU(hid_t file, vector<float>& mat, int rows, int cols, const string& name) {
+  WriteHDF5CPU(file, mat.data(), rows, cols, name);
+}
+void ReadHDF5Shape(hid_t file, const string& name, int* rows, int* cols) {
+  hid_t ds = H5Dopen2(file, name.c_str(), H5P_DEFAULT);
+  hid_t space = H5Dget_space(ds);
+  const int nd = H5Sget_simple_extent_ndims(space);
+  hsize_t dims[2] = {1, 1};
+  H5Sget_simple_extent_dims(space, dims, NULL);
+  *cols = (int)dims[0];
+  *rows = nd == 1 ? 1 : (int)dims[1];
+  H5Sclose(space);
+  H5Dclose(ds);
+}
+void ReadHDF5CPU(hid_t file, float* mat, int size, const string& name) {
+  int rows, cols;
+  ReadHDF5Shape(file, name, &rows, &cols);
+  if (rows * cols != size) {
+    std::cerr << "Dimension mismatch: Expected " << size << " Got " << rows << "-" << cols << std::endl;
+    exit(1);
+  }
+  hid_t ds = H5Dopen2(file, name.c_str(), H5P_DEFAULT);
+  H5Dread(ds, H5T_NATIVE_FLOAT, H5S_ALL, H5S_ALL, H5P_DEFAULT, mat);
+  H5Dclose(ds);
+}
+void WriteHDF5IntAttr(hid_t file, const string& name, const int* val) {
+  hid_t aid = H5Screate(H5S_SCALAR);
+  hid_t attr = H5Acreate2(file, name.c_str(), H5T_NATIVE_INT, aid, H5P_DEFAULT, H5P_DEFAULT);
+  H5Awrite(attr, H5T_NATIVE_INT, val);
+  H5Sclose(aid);
+  H5Aclose(attr);
+}
+void ReadHDF5IntAttr(hid_t file, const string& name, int* val) {
+  if (H5Aexists(file, name.c_str()) <= 0) return;
+  hid_t attr = H5Aopen(file, name.c_str(), H5P_DEFAULT);
+  H5Aread(attr, H5T_NATIVE_INT, val);
+  H5Aclose(attr);
+}
+
+ImageDisplayer::ImageDisplayer() {}
+ImageDisplayer::ImageDisplayer(int, int, int, bool, const string&) {}
+void ImageDisplayer::DisplayImage(float*, int, int) {}
+void ImageDisplayer::DisplayWeights(float*, int, int, int, bool) {}
+void ImageDisplayer::DisplayLocalization(float*, float*, float*, int) {}
+void ImageDisplayer::SetFOV(int, int, int, int, int, int, int) {}
+
+// ---- trampolines ---------------------------------------------------------------------------------------------------------
+namespace {
+// access to the pieces of ConvNet the tests read back (all protected members, so: a subclass)
+class SeamNet : public ConvNet {
+ public:
+  explicit SeamNet(const string& model_file) : ConvNet(model_file) {}
+  Matrix& Params() { return parameters_; }
+  Matrix& Grads() { return grad_parameters_; }
+  vector<Layer*>& Layers() { return layers_; }
+  void OneStep(vector<float>& err) { TrainOneBatch(err); }
+  float Loss() {   // what GradChecker::GetLoss reads (grad_check.cc:13-16), after the step's own Fprop
+    float s = 0.f;
+    for (Layer* l : output_layers_) s += l->GetLoss();
+    return s;
+  }
+  void ForwardBackward() {
+    for (Layer* l : layers_) l->ResetAddOrOverwrite();
+    GetBatch(*train_dataset_);
+    Fprop(true);
+    ComputeDeriv();
+    Bprop();
+  }
+  void NextBatch() { GetBatch(*train_dataset_); }
+};
+
+void setup_device() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+#ifdef USE_CUDA
+  Matrix::SetupCUDADevice(0);
+  SeamPools::ReleaseAtExit();
+#endif
+}
+}  // namespace
+
+extern "C" {
+
+// Builds the reference's ConvNet from `model_pbtxt` + `data_pbtxt`, copies `params_in` (if non-null; flat parameter buffer) in,
+// runs `steps` x TrainOneBatch, and returns the parameter buffer, the summed per-step train metric (correct count for softmax),
+// the per-step loss (loss_out[steps], read after each step's update) and the number of parameters.
+// With steps == 0 it runs one Fprop/ComputeDeriv/Bprop instead and returns the flat GRADIENT buffer in params_out.
+long seam_host_train(const char* model_pbtxt, const char* data_pbtxt, int steps, const float* params_in, float* params_out,
+                     long params_cap, float* metric_out, float* loss_out) {
+  setup_device();
+  SeamNet net(model_pbtxt);
+  net.SetupDataset(data_pbtxt);
+  net.AllocateMemory(false);
+  Matrix& P = net.Params();
+  const long n = (long)P.GetRows() * P.GetCols();
+  if (params_in) {
+    memcpy(P.GetHostData(), params_in, sizeof(float) * n);
+    P.CopyToDevice();
+  }
+  float metric = 0.f;
+  if (steps < 0) {   // just report the size and the reference's own initialisation
+    P.CopyToHost();
+    if (params_out && n <= params_cap) memcpy(params_out, P.GetHostData(), sizeof(float) * n);
+  } else if (steps == 0) {
+    net.ForwardBackward();
+    Matrix& G = net.Grads();
+    G.CopyToHost();
+    if (params_out && n <= params_cap) memcpy(params_out, G.GetHostData(), sizeof(float) * n);
+  } else {
+    vector<float> err;
+    for (int i = 0; i < steps; ++i) {
+      net.OneStep(err);
+      for (float e : err) metric += e;
+      if (loss_out) loss_out[i] = net.Loss();
+    }
+    P.CopyToHost();
+    if (params_out && n <= params_cap) memcpy(params_out, P.GetHostData(), sizeof(float) * n);
+  }
+  if (metric_out) *metric_out = metric;
+  return n;
+}
+
+// Batch number `index` as the data handler shim hands it to the net: input state (N x dims, column-major) and labels.
+long seam_host_batch(const char* model_pbtxt, const char* data_pbtxt, int index, float* x_out, long x_cap, float* y_out, long y_cap) {
+  setup_device();
+  SeamNet net(model_pbtxt);
+  net.SetupDataset(data_pbtxt);
+  net.AllocateMemory(false);
+  for (int i = 0; i <= index; ++i) net.NextBatch();
+  long nx = 0;
+  for (Layer* l : net.Layers()) {
+    if (l->IsInput()) {
+      Matrix& m = l->GetState();
+      m.CopyToHost();
+      nx = (long)m.GetRows() * m.GetCols();
+      if (x_out && nx <= x_cap) memcpy(x_out, m.GetHostData(), sizeof(float) * nx);
+    } else if (l->IsOutput()) {
+      Matrix& m = l->GetData();
+      m.CopyToHost();
+      const long ny = (long)m.GetRows() * m.GetCols();
+      if (y_out && ny <= y_cap) memcpy(y_out, m.GetHostData(), sizeof(float) * ny);
+    }
+  }
+  return nx;
+}
+
+// The reference's run_grad_check (apps/run_grad_check.cc): GradChecker on the model with its own grad_check flags.
+void seam_host_grad_check(const char* model_pbtxt, int batch_size, const char* output_h5) {
+  setup_device();
+  GradChecker gc(model_pbtxt);
+  gc.SetBatchsize(batch_size);
+  gc.AllocateMemory(false);
+  gc.Run(output_h5);
+}
+
+}  // extern "C"

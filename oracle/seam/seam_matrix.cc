@@ -15,6 +15,7 @@
 #include <string>
 
 #include "matrix.h"   // reference src/matrix.h (GPU flavour, -DUSE_GEMM)
+#include "seam_pools.h"
 
 std::string GetStringError(int err_code) {
   char buf[64];
@@ -58,6 +59,7 @@ void seam_init(int device) {
   if (done) return;
   done = true;
   Matrix::SetupCUDADevice(device);   // cuda_set_device + cublas_init + temp/ones bookkeeping (matrix.cc:486-532)
+  SeamPools::ReleaseAtExit();
 }
 
 // op 0: ConvUp(images a, filters b); 1: ConvDown(derivs a, filters b); 2: ConvOutp(images a, derivs b).  `out` carries the

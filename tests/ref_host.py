@@ -1,0 +1,122 @@
+"""Test helper: ctypes view of the reference's WHOLE host (ConvNet / GradChecker / Layer / Edge / Optimizer, compiled unmodified,
+oracle/Makefile target `host`, oracle/seam/seam_host.cc) in its two builds
+
+    oracle/_ref/libref_host_cpu.so   over the reference's CPU Matrix (CPUMatrix.cc + eigenmat)   — the whole-net oracle
+    oracle/_ref/libref_host_hip.so   over the reference's GPU Matrix (matrix.cc) + libconvnet_hip.so  — the drop-in demonstration
+
+and the numpy restatement of the batches oracle/seam/seam_datahandler.h feeds them."""
+import ctypes
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPU_SO = os.path.join(ROOT, "oracle", "_ref", "libref_host_cpu.so")
+HIP_SO = os.path.join(ROOT, "oracle", "_ref", "libref_host_hip.so")
+
+
+def hash_batch(seed, batch_index, n, is_input, classes=0):
+    """seam_datahandler.h GetBatch: lowbias32 of (base + flat element index); inputs uniform, zero mean, unit variance."""
+    base = (seed * 0x9E3779B1 + batch_index * 0x85EBCA77 + (0x1234567 if is_input else 0x7654321)) & 0xFFFFFFFF
+    x = (np.arange(n, dtype=np.uint64) + base).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    x *= np.uint32(0x7FEB352D)
+    x ^= x >> np.uint32(15)
+    x *= np.uint32(0x846CA68B)
+    x ^= x >> np.uint32(16)
+    if is_input:
+        return (((x >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0) - np.float32(0.5)) * np.float32(3.4641016)).astype(np.float32)
+    return (x % np.uint32(classes)).astype(np.float32)
+
+
+class RefHost:
+    def __init__(self, so_path, omp_threads=8):
+        self.lib = ctypes.CDLL(so_path)
+        if so_path == CPU_SO:
+            # eigenmat's OpenMP loops over these tiny layers: a team of every core of a big (or quota-limited) host costs far
+            # more in fork/join than the work itself
+            gomp = ctypes.CDLL("libgomp.so.1")
+            gomp.omp_set_num_threads(max(1, min(omp_threads, os.cpu_count() or 1)))
+        self.lib.seam_host_train.restype = ctypes.c_long
+        self.lib.seam_host_train.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long,
+                                             ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.seam_host_batch.restype = ctypes.c_long
+        self.lib.seam_host_batch.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long]
+        self.lib.seam_host_grad_check.restype = None
+        self.lib.seam_host_grad_check.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
+
+    def _call(self, model, data, steps, p_in, cap):
+        out = np.zeros(cap, np.float32) if cap else None
+        metric = ctypes.c_float()
+        loss = np.zeros(max(steps, 1), np.float32)
+        n = self.lib.seam_host_train(str(model).encode(), str(data).encode(), steps, None if p_in is None else p_in.ctypes.data,
+                                     None if out is None else out.ctypes.data, cap, ctypes.byref(metric), loss.ctypes.data)
+        assert cap == 0 or n <= cap
+        return (None if out is None else out[:n]), metric.value, loss[:max(steps, 0)], n
+
+    def init_params(self, model, data, cap=1 << 24):
+        """The reference's own random initialisation (Edge::Initialize), flat with its 128-float slice alignment."""
+        return self._call(model, data, -1, None, cap)[0].copy()
+
+    def gradient(self, model, data, params):
+        """One Fprop(train) / ComputeDeriv / Bprop on batch 0: the flat gradient buffer."""
+        return self._call(model, data, 0, np.ascontiguousarray(params), params.size)[0].copy()
+
+    def train(self, model, data, steps, params=None):
+        """`steps` x ConvNet::TrainOneBatch: (flat parameters, summed correct count, per-step loss).  params=None: start from
+        the reference's own initialisation and do not fetch the parameters (returns their count instead)."""
+        if params is None:
+            _, m, l, n = self._call(model, data, steps, None, 0)
+            return n, m, l.copy()
+        p, m, l, _ = self._call(model, data, steps, np.ascontiguousarray(params), params.size)
+        return p.copy(), m, l.copy()
+
+    def batch(self, model, data, index, dims, batch):
+        x, y = np.zeros(dims * batch, np.float32), np.zeros(batch, np.float32)
+        n = self.lib.seam_host_batch(str(model).encode(), str(data).encode(), index, x.ctypes.data, x.size, y.ctypes.data, y.size)
+        assert n == x.size
+        return x, y
+
+    def grad_check(self, model, batch, out_h5):
+        """apps/run_grad_check.cc: GradChecker::Run writing <edge>_{weights,bias}_{analytical,numerical} to `out_h5`."""
+        self.lib.seam_host_grad_check(str(model).encode(), batch, str(out_h5).encode())
+
+
+def write_configs(tmp, model_text, batch, num_batches, seed, name="net"):
+    m = os.path.join(str(tmp), name + ".pbtxt")
+    d = os.path.join(str(tmp), name + "_data.pbtxt")
+    with open(m, "w") as f:
+        f.write(model_text)
+    with open(d, "w") as f:   # seam_datahandler.h reads: batch_size, max_dataset_size (cases), chunk_size (= the data seed)
+        f.write(f"batch_size: {batch}\nmax_dataset_size: {batch * num_batches}\nchunk_size: {seed}\n")
+    return m, d
+
+
+def read_grad_check(path, edge_names):
+    """GradChecker output file -> {edge: {"weights"|"bias": (analytical[k], numerical[n_eps, k])}} (grad_check.cc:105-131)."""
+    from convnet_amd import hdf5io
+    out = {}
+    with hdf5io.File(path, "r") as f:
+        for e in edge_names:
+            out[e] = {}
+            for kind in ("weights", "bias"):
+                rows, cols = f.ReadHDF5Shape(f"{e}_{kind}_analytical")
+                a = np.asarray(f.ReadHDF5CPU(rows * cols, f"{e}_{kind}_analytical"), np.float32).reshape(-1)
+                rows, cols = f.ReadHDF5Shape(f"{e}_{kind}_numerical")
+                n = np.asarray(f.ReadHDF5CPU(rows * cols, f"{e}_{kind}_numerical"), np.float32).reshape(-1, a.size)
+                out[e][kind] = (a, n)
+    return out
+
+
+def grad_check_passes(a, n):
+    """GradChecker::GradCheck's criterion (grad_check.cc:41-64): some epsilon with mean |diff/scale| over non-zero entries < 1 %."""
+    best = np.inf
+    for row in n:
+        diff, scale = a - row, (a + row) / 2
+        nz = ~((scale == 0) & (diff == 0))
+        if nz.any():
+            with np.errstate(divide="ignore", invalid="ignore"):
+                best = min(best, float(np.mean(np.abs(diff[nz] / scale[nz]))))
+        else:
+            best = 0.0
+    return best < 0.01, best

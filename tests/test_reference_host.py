@@ -1,0 +1,250 @@
+"""The REFERENCE'S WHOLE HOST, compiled unmodified, as oracle and as drop-in demonstration.
+
+`make -C oracle host` compiles src/convnet.cc, grad_check.cc, layer.cc, loss_functions.cc, optimizer.cc, edge.cc,
+edge_with_weight.cc and every *_edge.cc from where they lie under /root/reference (nothing copied, nothing edited) twice:
+
+  oracle/_ref/libref_host_cpu.so — over the reference's CPU Matrix (src/CPUMatrix.cc + eigenmat): ConvNet::TrainOneBatch and
+      GradChecker::Run of the reference, on the CPU.  Its outputs on the AlexNet-topology test net are committed as
+      tests/golden/ref_host_tiny_alex.npz (tests/golden/make_ref_host_golden.py).
+  oracle/_ref/libref_host_hip.so — over the reference's GPU Matrix (src/matrix.cc, against the reference's own cudamat
+      headers) linked to convnet_amd/lib/libconvnet_hip.so: the reference's training step and its run_grad_check running on the
+      MI355X through this repo's C ABI, with no reference source change.
+
+CPU tests: the CPU build reproduces the golden file, its data shim equals the numpy restatement, it trains, its GradChecker runs.
+GPU tests: the HIP build's gradient / 3 training steps equal the golden file (i.e. the reference's CPU path) within the
+reference's own 1e-4; this repo's python host, fed the same batches and initial parameters, equals the reference host on the
+same library; the reference's GradChecker passes on the library; the reference host steps the full AlexNet on it."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import ref_host
+from golden_cases import rel_err
+from test_net_gpu import small_alexnet
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_host_tiny_alex.npz")
+GC_EDGES = ["input:c1", "r1:c2", "r2:c3", "c3:c4", "c4:c5", "p5:f6", "f6:f7", "f7:output"]
+IN_DIMS = 35 * 35 * 3
+TOL = 1e-4     # the reference's own GPU-vs-CPU tolerance (py/test_conv.py:382-392)
+
+
+@pytest.fixture(scope="module")
+def golden():
+    g = np.load(GOLDEN)
+    batch, num_batches, seed, steps = (int(v) for v in g["cfg"])
+    return dict(p0=g["p0"], g0=g["g0"], p3=g["p3"], loss3=g["loss3"], correct3=float(g["correct3"]), batch=batch,
+                num_batches=num_batches, seed=seed, steps=steps)
+
+
+@pytest.fixture(scope="module")
+def cpu_host():
+    if not os.path.exists(ref_host.CPU_SO):
+        pytest.skip("oracle/_ref/libref_host_cpu.so not built (needs the reference tree at build time)")
+    return ref_host.RefHost(ref_host.CPU_SO)
+
+
+@pytest.fixture(scope="module")
+def hip_host():
+    if not os.path.exists(ref_host.HIP_SO):
+        pytest.skip("oracle/_ref/libref_host_hip.so not built (needs the reference tree at build time)")
+    import torch
+    assert torch.cuda.is_available()
+    from convnet_amd import _lib     # loads libconvnet_hip.so after torch (one HIP runtime)
+    ctypes.CDLL(_lib.LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    return ref_host.RefHost(ref_host.HIP_SO)
+
+
+def slices(flat_size, text):
+    """(name, offset, size) of every parameterised edge in the flat buffer (src/convnet.cc:271-296), from the pbtxt alone."""
+    from convnet_amd import pbtxt
+    model = pbtxt.parse(text)
+    chans = {l.name: l.num_channels for l in model.layer}
+    size = {}
+    dests = {e.dest for e in model.edge}
+    for l in model.layer:
+        if l.name not in dests:     # an input layer: the only place the image size is stated
+            size[l.name] = (l.image_size_y, l.image_size_x)
+    out, off = [], 0
+    for e in model.edge:
+        sy, sx = size[e.source]
+        if e.edge_type in ("CONVOLUTIONAL", "MAXPOOL", "AVERAGE_POOL"):
+            k, s, p = e.kernel_size, e.stride, e.padding
+            size[e.dest] = ((sy + 2 * p - k) // s + 1, (sx + 2 * p - k) // s + 1)
+        elif e.edge_type == "FC":
+            size[e.dest] = (1, 1)
+        else:
+            size[e.dest] = (sy, sx)
+        if e.edge_type == "CONVOLUTIONAL":
+            n = chans[e.dest] * (e.kernel_size * e.kernel_size * chans[e.source] + 1)
+        elif e.edge_type == "FC":
+            n = chans[e.dest] * (sy * sx * chans[e.source] + 1)
+        else:
+            continue
+        out.append((f"{e.source}:{e.dest}", off, n))
+        off += ((n + 127) // 128) * 128
+    assert off == flat_size, (off, flat_size)
+    return out
+
+
+def assert_flat_close(got, want, text, tol, what):
+    for name, off, n in slices(want.size, text):
+        err = rel_err(got[off:off + n], want[off:off + n])
+        assert err < tol, (what, name, err)
+
+
+def grad_check_verdict(res):
+    """Same acceptance as tests/test_net_gpu.py::test_grad_check_passes: each check within the fp32 finite-difference noise
+    floor for some epsilon, and the reference's strict 1 % criterion for the clear majority."""
+    strict, total, bad = 0, 0, []
+    for e, kinds in res.items():
+        for kind, (a, n) in kinds.items():
+            total += 1
+            ok_strict, best = ref_host.grad_check_passes(a, n)
+            strict += ok_strict
+            ok = any(np.abs(a - row).max() <= 0.05 * np.abs(a).max() + 2e-4 for row in n if np.any(row))
+            if not (ok_strict or ok):
+                bad.append((e, kind, best, a, n))
+    return strict, total, bad
+
+
+# ---- CPU: the reference's host on the reference's CPU path ------------------------------------------------------------------
+
+def test_data_shim_batches_equal_the_numpy_restatement(cpu_host, golden, tmp_path):
+    m, d = ref_host.write_configs(tmp_path, small_alexnet(), golden["batch"], golden["num_batches"], golden["seed"])
+    for index in (0, 1, 2):      # 2 wraps to batch 0
+        x, y = cpu_host.batch(m, d, index, IN_DIMS, golden["batch"])
+        b = index % golden["num_batches"]
+        assert np.array_equal(x, ref_host.hash_batch(golden["seed"], b, x.size, True))
+        assert np.array_equal(y, ref_host.hash_batch(golden["seed"], b, y.size, False, 10))
+    assert abs(x.mean()) < 0.05 and abs(x.std() - 1.0) < 0.05
+
+
+def test_reference_cpu_host_reproduces_the_committed_golden_run(cpu_host, golden, tmp_path):
+    text = small_alexnet()
+    m, d = ref_host.write_configs(tmp_path, text, golden["batch"], golden["num_batches"], golden["seed"])
+    g0 = cpu_host.gradient(m, d, golden["p0"])
+    assert_flat_close(g0, golden["g0"], text, 1e-6, "gradient")
+    p3, correct, loss = cpu_host.train(m, d, golden["steps"], golden["p0"])
+    assert_flat_close(p3, golden["p3"], text, 1e-6, "parameters after 3 steps")
+    assert np.allclose(loss, golden["loss3"], rtol=1e-6) and correct == golden["correct3"]
+
+
+def test_reference_cpu_host_fits_a_fixed_batch(cpu_host, golden, tmp_path):
+    m, d = ref_host.write_configs(tmp_path, small_alexnet(), 8, 1, 3)
+    p, _, loss = cpu_host.train(m, d, 8, golden["p0"])
+    assert np.all(np.isfinite(p)) and np.all(np.diff(loss) < 0), loss
+
+
+def test_reference_grad_checker_runs_on_the_reference_cpu_path(cpu_host, tmp_path):
+    m, _ = ref_host.write_configs(tmp_path, small_alexnet(grad_check=True), 8, 1, 5, "gc")
+    out = os.path.join(str(tmp_path), "gc_cpu.h5")
+    cpu_host.grad_check(m, 8, out)
+    strict, total, bad = grad_check_verdict(ref_host.read_grad_check(out, GC_EDGES))
+    assert total == 2 * len(GC_EDGES) and not bad, bad
+    assert strict >= 0.5 * total, (strict, total)
+
+
+# ---- GPU: the reference's host on this library ------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_reference_host_on_this_library_matches_the_reference_cpu_run(hip_host, golden, tmp_path):
+    text = small_alexnet()
+    m, d = ref_host.write_configs(tmp_path, text, golden["batch"], golden["num_batches"], golden["seed"])
+    x, y = hip_host.batch(m, d, 1, IN_DIMS, golden["batch"])
+    assert np.array_equal(x, ref_host.hash_batch(golden["seed"], 1, x.size, True))
+    g0 = hip_host.gradient(m, d, golden["p0"])
+    assert_flat_close(g0, golden["g0"], text, TOL, "gradient")
+    p3, correct, loss = hip_host.train(m, d, golden["steps"], golden["p0"])
+    assert_flat_close(p3, golden["p3"], text, TOL, "parameters after 3 steps")
+    assert np.allclose(loss, golden["loss3"], rtol=TOL), (loss, golden["loss3"])
+    assert correct == golden["correct3"]
+
+
+class HashDataHandler:
+    """The data shim's batches for this repo's python host (same cycle: pos += batch, wrap when the next batch would not fit)."""
+
+    def __init__(self, net, batch, num_batches, seed):
+        from convnet_amd.matrix import Matrix
+        self.batch_size_, self.pos_, self.batches_ = batch, 0, []
+        for b in range(num_batches):
+            per = {}
+            for l in net.data_layers_:
+                m = Matrix()
+                if l.IsInput():
+                    dims = l.GetSizeY() * l.GetSizeX() * l.GetSizeT() * l.GetNumChannels()
+                    m.AllocateGPUMemory(batch, dims)
+                    m.FromNumpy(ref_host.hash_batch(seed, b, dims * batch, True).reshape(dims, batch))
+                else:
+                    m.AllocateGPUMemory(batch, 1)
+                    m.FromNumpy(ref_host.hash_batch(seed, b, batch, False, l.GetNumChannels()))
+                per[l.GetName()] = m
+            self.batches_.append(per)
+
+    def GetBatchSize(self):
+        return self.batch_size_
+
+    def GetDataSetSize(self):
+        return self.batch_size_ * len(self.batches_)
+
+    def Seek(self, row):
+        self.pos_ = row // self.batch_size_
+
+    def Sync(self):
+        pass
+
+    def GetBatch(self, data_layers):
+        b = self.batches_[self.pos_ % len(self.batches_)]
+        self.pos_ += 1
+        for l in data_layers:
+            (l.GetState() if l.IsInput() else l.GetData()).Set(b[l.GetName()])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True], ids=["unfused", "fused"])
+def test_python_host_equals_the_reference_host_on_the_same_library(hip_host, golden, tmp_path, fused):
+    """Same pbtxt, same initial parameters, same batches: this repo's ConvNet (convnet_amd/convnet.py) against the
+    reference's ConvNet (src/convnet.cc), both on libconvnet_hip.so.  Unfused, the two issue the same ABI calls; fused, the
+    python host uses the fused entries (bias row in wgrad, ReLU in rnorm, one-kernel SGD)."""
+    from convnet_amd.convnet import ConvNet
+    from convnet_amd.matrix import Matrix
+    Matrix.SetupCUDADevice(0)
+    text = small_alexnet()
+    m, d = ref_host.write_configs(tmp_path, text, golden["batch"], golden["num_batches"], golden["seed"])
+    ref_p3, _, ref_loss = hip_host.train(m, d, golden["steps"], golden["p0"])
+
+    net = ConvNet(text, fused=fused)
+    net.SetBatchsize(golden["batch"])
+    net.SetupDataset(HashDataHandler(net, golden["batch"], golden["num_batches"], golden["seed"]))
+    net.AllocateMemory(False)
+    assert net.parameters_.GetNumEls() == golden["p0"].size
+    net.parameters_.FromNumpy(golden["p0"].reshape(1, -1))
+    for _ in range(golden["steps"]):
+        net.TrainOneBatch()
+    p3 = net.parameters_.ToNumpy().reshape(-1)
+    assert_flat_close(p3, ref_p3, text, 2e-5 if fused else 2e-6, "python host vs reference host")
+    assert_flat_close(p3, golden["p3"], text, TOL, "python host vs reference CPU run")
+
+
+@pytest.mark.gpu
+def test_reference_grad_checker_passes_on_this_library(hip_host, tmp_path):
+    """apps/run_grad_check.cc's body — the acceptance gate BASELINE.json names — with the reference's own GradChecker."""
+    m, _ = ref_host.write_configs(tmp_path, small_alexnet(grad_check=True), 8, 1, 5, "gc")
+    out = os.path.join(str(tmp_path), "gc_hip.h5")
+    hip_host.grad_check(m, 8, out)
+    strict, total, bad = grad_check_verdict(ref_host.read_grad_check(out, GC_EDGES))
+    assert total == 2 * len(GC_EDGES) and not bad, bad
+    assert strict >= 0.5 * total, (strict, total)
+
+
+@pytest.mark.gpu
+def test_reference_host_steps_the_full_alexnet_on_this_library(hip_host, tmp_path):
+    """The north-star model itself (the reference's CLS_net pbtxt as convnet_amd.models restates it, dropout on), batch 32,
+    driven by the reference's ConvNet::TrainOneBatch through the reference's Matrix onto this library."""
+    from convnet_amd import models
+    m, d = ref_host.write_configs(tmp_path, models.alexnet(), 32, 2, 11, "alexnet")
+    n, correct, loss = hip_host.train(m, d, 4)
+    assert n > 60_000_000                      # the AlexNet-class parameter count (flat, aligned)
+    assert np.all(np.isfinite(loss)) and 0 <= correct <= 4 * 32
+    assert np.all(loss < 32 * 12.0)            # log(1000) = 6.9 per case at init; no blow-up
