@@ -133,6 +133,33 @@ __global__ void colsum_wave_kernel(const float* __restrict__ mat, float* __restr
   if (l == 0) target[j] = (p != 0.f ? p * target[j] : 0.f) + mult * s;
 }
 
+// many short columns (the reference's two-step shared-bias gradient sums a (batch, pixels*filters) matrix over the batch first,
+// src/conv_edge.cc:213-218: 1.16 M columns of 256 for conv1): float4 loads, 8 columns per wave so 8 loads are in flight before
+// the first cross-lane reduction.
+template <bool SQ>
+__global__ void colsum_wave4_kernel(const float* __restrict__ mat, float* __restrict__ target, int rows, int cols, float mult, float p) {
+  const int l = threadIdx.x & 63;
+  const int j0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+  const int r4 = rows >> 2;
+  float s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    s[u] = 0.f;
+    if (j0 + u < cols) {
+      const f32x4* c4 = reinterpret_cast<const f32x4*>(mat + (size_t)(j0 + u) * rows);
+      for (int i = l; i < r4; i += 64) {
+        const f32x4 v = c4[i];
+        s[u] += SQ ? (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]) : (v[0] + v[1]) + (v[2] + v[3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const float t = wave_sum(s[u]);
+    if (l == 0 && j0 + u < cols) target[j0 + u] = (p != 0.f ? p * target[j0 + u] : 0.f) + mult * t;
+  }
+}
+
 // target[i] = p*target[i] + mult * sum_j g(mat[i + rows*j]) : one thread per row, coalesced over rows.
 template <bool SQ>
 __global__ void rowsum_kernel(const float* __restrict__ mat, float* __restrict__ target, int rows, int cols, float mult, float p) {
@@ -165,6 +192,8 @@ int axis_sum(cudamat* mat, cudamat* target, int axis, float mult, float p) {
       hipLaunchKernelGGL(colsum_finish_kernel, dim3(divup(cols, 256)), dim3(256), 0, stream(), part, target->data_device, cols, splits, mult, p);
     } else if (rows >= 2048)
       hipLaunchKernelGGL(colsum_block_kernel<SQ>, dim3(cols), dim3(256), 0, stream(), mat->data_device, target->data_device, rows, mult, p);
+    else if ((rows & 3) == 0 && rows >= 128 && cols >= 4096 && (reinterpret_cast<uintptr_t>(mat->data_device) & 15) == 0)
+      hipLaunchKernelGGL(colsum_wave4_kernel<SQ>, dim3(divup(cols, 32)), dim3(256), 0, stream(), mat->data_device, target->data_device, rows, cols, mult, p);
     else
       hipLaunchKernelGGL(colsum_wave_kernel<SQ>, dim3(divup(cols, 4)), dim3(256), 0, stream(), mat->data_device, target->data_device, rows, cols, mult, p);
   } else if (axis == 1) {
@@ -443,16 +472,31 @@ __global__ void softmax_grad_kernel(const float* __restrict__ labels, float* __r
   if (i < rows) target[(size_t)i + (size_t)rows * (int)labels[i]] -= 1.0f;
 }
 
-__global__ void softmax_correct_kernel(const float* __restrict__ mat, const float* __restrict__ labels, float* __restrict__ target, int rows, int cols) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows) return;
-  int am = 0;
-  float best = mat[i];
-  for (int j = 1; j < cols; ++j) {
-    const float v = mat[(size_t)j * rows + i];
-    if (best < v) { best = v; am = j; }
+// 32 rows x 32 column-lanes per block: lane c scans columns c, c+32, ... (coalesced over the 32 rows), then the 32 candidates of a
+// row are reduced in LDS.  First maximum wins, as a sequential scan with `best < v` would pick it (cudamat.cu softmax-correct kernel).
+__global__ void __launch_bounds__(1024) softmax_correct_kernel(const float* __restrict__ mat, const float* __restrict__ labels, float* __restrict__ target, int rows, int cols) {
+  __shared__ float sv[32][33];
+  __shared__ int si[32][33];
+  const int r = threadIdx.x & 31, c = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + r;
+  float best = -INFINITY;
+  int am = 0x7fffffff;
+  if (i < rows)
+    for (int j = c; j < cols; j += 32) {
+      const float v = mat[(size_t)j * rows + i];
+      if (am == 0x7fffffff || best < v) { best = v; am = j; }
+    }
+  sv[r][c] = best;
+  si[r][c] = am;
+  __syncthreads();
+  if (c == 0 && i < rows) {
+    for (int k = 1; k < 32; ++k) {
+      const float v = sv[r][k];
+      const int j = si[r][k];
+      if (j != 0x7fffffff && (best < v || (v == best && j < am))) { best = v; am = j; }
+    }
+    target[i] = ((int)labels[i] == am) ? 1.f : 0.f;
   }
-  target[i] = ((int)labels[i] == am) ? 1.f : 0.f;
 }
 
 __global__ void softmax_ce_kernel(const float* __restrict__ mat, const float* __restrict__ labels, float* __restrict__ target, int rows, float tiny) {
@@ -674,7 +718,7 @@ int get_softmax_correct_row_major(cudamat* mat, cudamat* labels, cudamat* target
   if (!mat->on_device || !labels->on_device || !target->on_device) return ERROR_NOT_ON_DEVICE;
   if (mat->is_trans) return ERROR_TRANSPOSED;
   if (target->size[0] != mat->size[0] || target->size[1] != 1 || numel(labels) != (size_t)mat->size[0]) return ERROR_INCOMPATIBLE_DIMENSIONS;
-  hipLaunchKernelGGL(softmax_correct_kernel, dim3(divup(mat->size[0], 64)), dim3(64), 0, stream(), mat->data_device, labels->data_device,
+  hipLaunchKernelGGL(softmax_correct_kernel, dim3(divup(mat->size[0], 32)), dim3(1024), 0, stream(), mat->data_device, labels->data_device,
                      target->data_device, mat->size[0], mat->size[1]);
   return launch_status();
 }

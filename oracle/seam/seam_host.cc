@@ -218,6 +218,26 @@ long seam_host_train(const char* model_pbtxt, const char* data_pbtxt, int steps,
   return n;
 }
 
+// Wall-clock of the reference's own training loop body (ConvNet::TrainOneBatch, src/convnet.cc:475-485, including its per-step
+// GetLoss read-back) on whichever Matrix this build links: `warmup` untimed steps, then `steps` timed between device syncs.
+// Returns milliseconds per step; the last step's loss goes to loss_out[0].
+double seam_host_bench(const char* model_pbtxt, const char* data_pbtxt, int warmup, int steps, float* loss_out) {
+  setup_device();
+  SeamNet net(model_pbtxt);
+  net.SetupDataset(data_pbtxt);
+  net.AllocateMemory(false);
+  vector<float> err;
+  for (int i = 0; i < warmup; ++i) net.OneStep(err);
+  Matrix::SyncAllDevices();
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int i = 0; i < steps; ++i) net.OneStep(err);
+  Matrix::SyncAllDevices();
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (loss_out) loss_out[0] = net.Loss();
+  return ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6) / (steps > 0 ? steps : 1);
+}
+
 // Batch number `index` as the data handler shim hands it to the net: input state (N x dims, column-major) and labels.
 long seam_host_batch(const char* model_pbtxt, const char* data_pbtxt, int index, float* x_out, long x_cap, float* y_out, long y_cap) {
   setup_device();

@@ -221,6 +221,12 @@ def test_elementwise_reductions_and_views(hip):
     big = rnd(rng, (3, 5000))   # long columns: block-per-column path
     t0 = np.zeros(3, np.float32)
     assert rel_err(hip.sum_by_axis(big, t0.copy(), 0, 1.0, 0.0), oracle.port.sum_by_axis(big, t0.copy(), 0, 1.0, 0.0)) < 1e-5
+    # many short columns (the reference's two-step shared-bias gradient, src/conv_edge.cc:213-218): float4 wave path, with a
+    # column count that is not a multiple of the 32 columns a block takes, and one shape that must stay on the scalar path
+    for rows, cols in ((256, 4099), (132, 5000), (130, 4100)):
+        many = rnd(rng, (cols, rows))
+        t0 = rnd(rng, (cols,))
+        assert rel_err(hip.sum_by_axis(many, t0.copy(), 0, 0.25, 0.5), oracle.port.sum_by_axis(many, t0.copy(), 0, 0.25, 0.5)) < 1e-5
     assert np.array_equal(hip.lower_bound(a.copy(), 0.0), oracle.port.lower_bound(a.copy(), 0.0))
     assert np.array_equal(hip.upper_bound_mod(a.copy(), 0.4), oracle.port.upper_bound_mod(a.copy(), 0.4))
     st = np.maximum(rnd(rng, a.shape), 0)
