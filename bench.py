@@ -34,6 +34,30 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(kernel, args):
+    """`roofline.traffic`: fabric-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+    same workload (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 half-count corrected: tools/pmc_traffic.py).  PMC
+    collection needs rocprofv3 around the process, so the figure is read from profiles/, newest round first; null when the
+    workload is not the profiled one."""
+    import glob
+    if args.model != "alexnet" or args.batch != 256 or args.unfused:
+        return {"traffic": None}
+    want = kernel.replace(" ", "")
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic_bench.json")), reverse=True):
+        try:
+            with open(path) as f:
+                kernels = json.load(f)["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for name, rec in kernels.items():
+            # bench names a family "gg_kernel<2,2,2,128,rc>"; the PMC file has the full template argument list
+            fam = name.replace(" ", "")
+            if fam.startswith(want.split(",rc")[0].split(",kc")[0]) and (",true,true," in fam) == want.endswith(",kc>"):
+                return {"traffic": rec["traffic_bytes"], "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, fabric side)",
+                        "traffic_source": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))}
+    return {"traffic": None}
+
+
 def cpu_baseline(sample_n=6):   # ~13 s of CPU work on the 256-core GPU box (N=2 took 4.1-4.7 s; the cost is linear in N)
     """Time the reference CPU path on the AlexNet-class training step at a reduced batch.
     Test infrastructure used strictly as a *baseline*, never as the thing measured above."""
@@ -221,7 +245,8 @@ def main():
             all_ms = sum(v["ms"] for v in mfma.values())
             roofline = {
                 "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
+                **pmc_traffic(dom_name, args),
                 "flops_per_launch": dom["flops"] / dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                 "launches": dom["launches"], "sampled_steps": timed_steps,
                 "all_mfma_kernels": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),

@@ -209,7 +209,17 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
     if (b >= ct.c[ct.n - 1].tile_end) return;
     int c = 0;
     while (b >= ct.c[c].tile_end) ++c;
-    L = b - (c > 0 ? ct.c[c - 1].tile_end : 0);
+    const int cbeg = c > 0 ? ct.c[c - 1].tile_end : 0;
+    {
+      // XCD-aware order inside the class (hardware places block b on XCD b%8): the blocks of this class that land on one XCD
+      // take a CONTIGUOUS run of its logical tiles, so neighbouring pixels — which gather overlapping taps — share one L2.
+      // Without it every XCD saw pixels 8 apart and conv2's dgrad fetched each deriv element once per tap (4.2 GiB for a
+      // 169 MiB tensor, profiles/r01_pmc_traffic_bench.json).  Exact counts, no padding blocks: residue r = i%8 owns
+      // q + (r < m) tiles starting at r*q + min(r, m).
+      const int i = b - cbeg, T = ct.c[c].tile_end - cbeg;
+      const int q = T >> 3, m = T & 7, r = i & 7;
+      L = r * q + (r < m ? r : m) + (i >> 3);
+    }
     const GGClass& k = ct.c[c];
     pA = k.A; pK = k.K; pGX = k.GX; pG = k.G; pTX = k.TX; pTYX = k.TYX;
     py0 = k.y0; px0 = k.x0; pdy0 = k.dy0; pdx0 = k.dx0; pncols = k.ncols; pcol_tiles = k.col_tiles;
