@@ -17,7 +17,30 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 struct PoolGeo {
   int N, C, H, W, Ky, Kx, sy, sx, py, px, My, Mx;
   int nvec;  // ceil(N/4)
+  // XCD-aware block order of the fixed-window kernels (0 = plain 3-D grid): see pool_block()
+  int xper, xtotal, xrows, xbx;
 };
+
+// Fixed-window kernels, block -> (x-block, row, channel).  A 3x3 stride-2 window shares an input row with the window below
+// it, and with the plain (x, row, channel) grid those two blocks sit 14 block ids apart, i.e. on different XCDs (hardware
+// places block b on XCD b%8): the shared row is fetched twice from the fabric — measured 1.67x the algorithmic read bytes for
+// pool1 forward and undo (profiles/r01_pmc_traffic_bench.json), which puts both kernels on the memory system's ceiling.
+// With the 1-D launch each XCD owns a contiguous run of logical blocks ordered ROW-fastest, so the rows a block shares with
+// its vertical neighbours are requested by the same XCD back to back and the second request hits its L2.
+__device__ __forceinline__ bool pool_block(const PoolGeo& g, int& bx, int& row, int& c) {
+  if (g.xper == 0) {
+    bx = blockIdx.x; row = blockIdx.y; c = blockIdx.z;
+    return true;
+  }
+  const int b = blockIdx.x, slot = b >> 3;
+  const int L = (b & 7) * g.xper + slot;
+  if (slot >= g.xper || L >= g.xtotal) return false;
+  row = L % g.xrows;
+  const int t = L / g.xrows;
+  bx = t % g.xbx;
+  c = t / g.xbx;
+  return true;
+}
 
 __device__ __forceinline__ f32x4 ldv(const float* p, int n, int N, bool vec) {
   if (vec) return *reinterpret_cast<const f32x4*>(p);
@@ -132,10 +155,11 @@ __global__ void pool_undo_kernel(const float* __restrict__ images, const float* 
 template <bool MAX, int K, int S>
 __global__ void __launch_bounds__(256) pool_fwd_fixed_kernel(const float* __restrict__ in, float* __restrict__ out, PoolGeo g, float st,
                                                              float so) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  int bx, oy, c;
+  if (!pool_block(g, bx, oy, c)) return;
+  const int j = bx * 256 + threadIdx.x;
   if (j >= g.Mx * g.nvec) return;
   const int ox = j / g.nvec, n = 4 * (j - ox * g.nvec);
-  const int oy = blockIdx.y, c = blockIdx.z;
   const int ys = oy * S + g.py, xs = ox * S + g.px;
   const float* plane = in + (size_t)c * g.H * g.W * g.N + n;
   f32x4 v[K][K];
@@ -176,10 +200,11 @@ __global__ void __launch_bounds__(256) pool_undo_fixed_kernel(const float* __res
                                                               const float* __restrict__ acts, float* __restrict__ out, PoolGeo g, float st,
                                                               bool relu_mask) {
   constexpr int CV = (K + S - 1) / S;   // pooled coordinates that can cover one input coordinate
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  int bx, iy, c;
+  if (!pool_block(g, bx, iy, c)) return;
+  const int j = bx * 256 + threadIdx.x;
   if (j >= g.W * g.nvec) return;
   const int ix = j / g.nvec, n = 4 * (j - ix * g.nvec);
-  const int iy = blockIdx.y, c = blockIdx.z;
   const size_t t = ((size_t)(c * g.H + iy) * g.W + ix) * g.N + n;
   f32x4 img = {0.f, 0.f, 0.f, 0.f};
   if (MAX) img = *reinterpret_cast<const f32x4*>(images + t);
@@ -498,6 +523,7 @@ PoolGeo pool_geo(const Shape4D* in, const Shape4D* out, const ConvDesc& d, const
   g.Mx = out->shape[1]; g.My = out->shape[2];
   g.Ky = d.kernel_size_y; g.Kx = d.kernel_size_x; g.sy = d.stride_y; g.sx = d.stride_x; g.py = d.padding_y; g.px = d.padding_x;
   g.nvec = divup(g.N, 4);
+  g.xper = g.xtotal = g.xrows = g.xbx = 0;
   CHIP_REQUIRE(out->shape[0] == g.N && out->shape[3] == g.C);
   CHIP_REQUIRE(d.num_input_channels == g.C && d.num_output_channels == g.C);  // cudamat_conv_gemm.cu:1150-1160
   CHIP_REQUIRE(mi->size[0] == g.N && mi->size[1] == g.H * g.W * g.C);
@@ -514,15 +540,25 @@ inline int fixed_window(const PoolGeo& g, bool vec) {
   return 0;
 }
 
+// Switches a fixed-window launch to the XCD-aware 1-D order (CONVNET_POOL_NO_XCD=1 keeps the plain 3-D grid, for A/B runs).
+inline dim3 pool_xcd_grid(PoolGeo& g, int xblocks, int rows, dim3 plain) {
+  static const bool off = [] { const char* e = getenv("CONVNET_POOL_NO_XCD"); return e && *e && *e != '0'; }();
+  const long long total = (long long)xblocks * rows * g.C;
+  if (off || total < 64 || total > (1ll << 30)) return plain;
+  g.xbx = xblocks; g.xrows = rows; g.xtotal = (int)total; g.xper = (int)((total + 7) / 8);
+  return dim3(8 * g.xper);
+}
+
 template <bool MAX>
 void pool_fwd(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, const ConvDesc& d, float st, float so) {
-  const PoolGeo g = pool_geo(is, ts, d, images, targets);
+  PoolGeo g = pool_geo(is, ts, d, images, targets);
   const bool vec = g.N % 4 == 0 && a16(images->data_device) && a16(targets->data_device);
   const size_t total = (size_t)g.C * g.My * g.Mx * g.nvec;
   // algorithmic bytes: read input once, write output once
   KernelTimer timer(MAX ? "pool_fwd_kernel<max>" : "pool_fwd_kernel<avg>", "pool_fwd", 0.0, 4.0 * g.N * g.C * ((double)g.H * g.W + (double)g.My * g.Mx));
   const int fx = fixed_window(g, vec);
-  const dim3 fgrid(divup(g.Mx * g.nvec, 256), g.My, g.C);
+  dim3 fgrid(divup(g.Mx * g.nvec, 256), g.My, g.C);
+  if (fx) fgrid = pool_xcd_grid(g, fgrid.x, g.My, fgrid);
   if (fx == 32)
     hipLaunchKernelGGL((pool_fwd_fixed_kernel<MAX, 3, 2>), fgrid, dim3(256), 0, stream(), images->data_device, targets->data_device, g, st, so);
   else if (fx == 22)
@@ -535,7 +571,7 @@ void pool_fwd(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, const
 template <bool MAX>
 void pool_undo(cudamat* images, cudamat* grads, cudamat* acts, cudamat* targets, Shape4D* in_shape, Shape4D* pooled_shape,
                const ConvDesc& d, float st, bool relu_mask = false) {
-  const PoolGeo g = pool_geo(in_shape, pooled_shape, d, targets, grads);
+  PoolGeo g = pool_geo(in_shape, pooled_shape, d, targets, grads);
   const bool vec = g.N % 4 == 0 && a16(grads->data_device) && a16(targets->data_device) &&
                    (!MAX || (a16(images->data_device) && a16(acts->data_device)));
   const size_t total = (size_t)g.C * g.H * g.W * g.nvec;
@@ -544,7 +580,8 @@ void pool_undo(cudamat* images, cudamat* grads, cudamat* acts, cudamat* targets,
   const float* im = MAX ? images->data_device : nullptr;
   const float* ac = MAX ? acts->data_device : nullptr;
   const int fx = fixed_window(g, vec);
-  const dim3 fgrid(divup(g.W * g.nvec, 256), g.H, g.C);
+  dim3 fgrid(divup(g.W * g.nvec, 256), g.H, g.C);
+  if (fx) fgrid = pool_xcd_grid(g, fgrid.x, g.H, fgrid);
   if (fx == 32)
     hipLaunchKernelGGL((pool_undo_fixed_kernel<MAX, 3, 2>), fgrid, dim3(256), 0, stream(), im, grads->data_device, ac, targets->data_device, g,
                        st, relu_mask);
