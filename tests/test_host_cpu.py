@@ -167,3 +167,26 @@ def test_nin_model_graph_and_work_count():
     assert e.GetParameterMemoryRequirement() == 768 * (384 + 1)
     fwd, train = models.count_macs(net)
     assert fwd == 2035639424 and train == 5936163072
+
+
+def test_pmc_traffic_summary_is_reproducible_from_the_committed_counter_files():
+    """profiles/r01_pmc_traffic_bench.json (what bench.py reports as roofline.traffic) == tools/pmc_traffic.py over the two
+    committed rocprofv3 counter files, and the calibration kernels behave as DESIGN.md section 5 states."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_traffic.py"),
+                          os.path.join(prof, "r01_pmc_FETCH_SIZE_counter_collection.csv"),
+                          os.path.join(prof, "r01_pmc_WRITE_SIZE_counter_collection.csv")], capture_output=True, text=True, check=True)
+    got = json.loads(out.stdout)
+    with open(os.path.join(prof, "r01_pmc_traffic_bench.json")) as f:
+        want = json.load(f)
+    assert got["kernels"] == want["kernels"]
+    k = got["kernels"]
+    # rnorm1 forward reads its 290 400 KiB input once and writes as much: the doubled FETCH_SIZE must equal WRITE_SIZE
+    rn = k["rnorm_fwd_lds_kernel<64>"]
+    assert rn["write_size_kib_raw"] == 290400.0 and abs(2 * rn["fetch_size_kib_raw"] / 290400.0 - 1.0) < 0.01
+    dom = k["gg_kernel<2, 2, 2, 128, false, true, false>"]
+    assert dom["launches"] == 40 and 3.0e8 < dom["traffic_bytes"] < 4.0e8
