@@ -132,3 +132,63 @@ def test_sgd_step(limit, constraint):
     oracle.ref.sgd_step(*b, 5e-4, 0.9, 0.01, 0.7, limit, constraint)
     for u, v in zip(a, b):
         assert rel(u, v) < 1e-6
+
+
+def test_random_conv_geometries_port_equals_reference():
+    """Seeded sweep over 40 geometries (rectangular maps and kernels, stride 1-3 per axis, padding up to kernel/2, N and F not
+    multiples of 4): the restatement must follow the reference's CPU conv for all three passes, with and without accumulation."""
+    rng = np.random.default_rng(2024)
+    done = 0
+    while done < 40:
+        Ky, Kx = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        sy, sx = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        pady, padx = int(rng.integers(0, Ky // 2 + 1)), int(rng.integers(0, Kx // 2 + 1))
+        H, W = int(rng.integers(Ky, Ky + 9)), int(rng.integers(Kx, Kx + 9))
+        g = Geom(N=int(rng.integers(1, 10)), C=int(rng.integers(1, 7)), H=H, W=W, F=int(rng.integers(1, 10)), Ky=Ky, Kx=Kx, sy=sy, sx=sx,
+                 pady=pady, padx=padx)
+        if g.My < 1 or g.Mx < 1:
+            continue
+        done += 1
+        x, w, dy = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape()), rnd(rng, g.out_shape())
+        st = float(done % 2)
+        t0 = rnd(rng, g.out_shape())
+        assert rel(oracle.port.conv_up(g, x, w, t0.copy(), st, 1.0), oracle.ref.conv_up(g, x, w, t0.copy(), st, 1.0)) < 2e-6, g
+        t0 = rnd(rng, g.in_shape())
+        assert rel(oracle.port.conv_down(g, dy, w, t0.copy(), st, 1.0), oracle.ref.conv_down(g, dy, w, t0.copy(), st, 1.0)) < 2e-6, g
+        t0 = rnd(rng, g.filt_shape())
+        assert rel(oracle.port.conv_outp(g, x, dy, t0.copy(), st, 0.5), oracle.ref.conv_outp(g, x, dy, t0.copy(), st, 0.5)) < 2e-6, g
+
+
+def test_random_square_pool_and_rnorm_port_equals_reference():
+    """Seeded sweep: 30 square pooling set-ups (the reference's CPU undo assumes square maps and kernels) with post-ReLU ties, and
+    20 response-norm set-ups (window 1..C, blocked and sliding)."""
+    rng = np.random.default_rng(77)
+    done = 0
+    while done < 30:
+        K, s = int(rng.integers(2, 5)), int(rng.integers(1, 4))
+        pad = int(rng.integers(0, K // 2 + 1))
+        H = int(rng.integers(K, K + 10))
+        C = int(rng.integers(1, 6))
+        g = Geom(N=int(rng.integers(1, 9)), C=C, H=H, W=H, F=C, Ky=K, Kx=K, sy=s, sx=s, pady=pad, padx=pad)
+        if g.My < 1 or (g.My - 1) * s - pad >= H:     # every window must touch the map
+            continue
+        done += 1
+        x = np.maximum(rnd(rng, g.in_shape()), 0)
+        dy = rnd(rng, g.pooled_shape())
+        a, b = oracle.port.max_pool(g, x), oracle.ref.max_pool(g, x)
+        assert np.array_equal(a, b), g
+        assert rel(oracle.port.avg_pool(g, x), oracle.ref.avg_pool(g, x)) < 1e-6, g
+        st = float(done % 2)
+        t0 = rnd(rng, g.in_shape())
+        assert rel(oracle.port.max_pool_undo(g, x, dy, a, t0.copy(), st), oracle.ref.max_pool_undo(g, x, dy, b, t0.copy(), st)) < 1e-6, g
+        assert rel(oracle.port.avg_pool_undo(g, dy, t0.copy(), st), oracle.ref.avg_pool_undo(g, dy, t0.copy(), st)) < 1e-6, g
+    for i in range(20):
+        C = int(rng.integers(2, 40))
+        size_f = int(rng.integers(1, C + 1))
+        blocked = bool(i % 3 == 0)
+        x = rnd(rng, (C, int(rng.integers(1, 5)), int(rng.integers(1, 5)), int(rng.integers(1, 9))))
+        dy = rnd(rng, x.shape)
+        a, b = oracle.port.rnorm(x, size_f, 0.005, 0.75, blocked), oracle.ref.rnorm(x, size_f, 0.005, 0.75, blocked)
+        assert rel(a, b) < 2e-6, (C, size_f, blocked)
+        u, v = oracle.port.rnorm_undo(dy, x, size_f, 0.005, 0.75, blocked), oracle.ref.rnorm_undo(dy, x, size_f, 0.005, 0.75, blocked)
+        assert rel(u, v) < 1e-5, (C, size_f, blocked)
