@@ -190,3 +190,48 @@ def test_pmc_traffic_summary_is_reproducible_from_the_committed_counter_files():
     assert rn["write_size_kib_raw"] == 290400.0 and abs(2 * rn["fetch_size_kib_raw"] / 290400.0 - 1.0) < 0.01
     dom = k["gg_kernel<2, 2, 2, 128, false, true, false>"]
     assert dom["launches"] == 40 and 3.0e8 < dom["traffic_bytes"] < 4.0e8
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/proto/convnet_config.proto"), reason="reference tree not mounted")
+def test_pbtxt_schema_matches_the_reference_proto_field_for_field():
+    """convnet_amd/pbtxt.py restates proto/convnet_config.proto by hand: every field of Layer / Edge / Optimizer / Model (and
+    LayerSlice) must exist with the proto's default, so a reference pbtxt means the same thing to both hosts.  The proto is
+    parsed with the same reader the seam build uses to generate its C++ config classes (oracle/seam/gen_config_pb.py)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_config_pb", os.path.join(root, "oracle", "seam", "gen_config_pb.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    from convnet_amd import pbtxt
+    with open("/root/reference/proto/convnet_config.proto") as f:
+        msgs = {m.name: m for m in gen.flatten(gen.parse(f.read()))}
+    out_of_scope = {"Model": {"subnet", "train_dataset", "valid_dataset"}}   # sub-net merging and dataset configs: not on the path
+    for name, cls in (("Layer", pbtxt.Layer), ("Edge", pbtxt.Edge), ("Optimizer", pbtxt.Optimizer), ("Model", pbtxt.Model),
+                      ("LayerSlice", pbtxt.LayerSlice)):
+        proto = {f["name"]: f for f in msgs[name].fields}
+        enums = {e: [v for v, _ in vals] for m in msgs.values() for e, vals in m.enums}
+        assert set(proto) - set(cls.FIELDS) == out_of_scope.get(name, set()), name
+        assert not set(cls.FIELDS) - set(proto), name
+        for key, mine in cls.FIELDS.items():
+            f = proto[key]
+            if f["label"] == "repeated":
+                assert mine is list or (isinstance(mine, tuple) and mine[0] is list), (name, key)
+                continue
+            if isinstance(mine, type):                       # sub-message
+                assert f["type"] == mine.__name__, (name, key)
+                continue
+            d = f["default"]
+            if f["type"] == "string":
+                want = "" if d is None else d.strip('"')
+            elif f["type"] == "bool":
+                want = d == "true"
+            elif f["type"] in ("float", "double"):
+                want = 0.0 if d is None else float(d)
+            elif f["type"] in gen.SCALARS:
+                want = 0 if d is None else int(d)
+            else:                                            # enum: declared default, else its first value (proto2)
+                want = d if d is not None else enums[f["type"].split(".")[-1]][0]
+            if isinstance(want, float):
+                assert abs(float(mine) - want) <= 1e-9 * max(1.0, abs(want)), (name, key, mine, want)
+            else:
+                assert mine == want and type(mine) is type(want), (name, key, mine, want)
