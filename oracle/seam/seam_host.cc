@@ -262,6 +262,32 @@ long seam_host_batch(const char* model_pbtxt, const char* data_pbtxt, int index,
   return nx;
 }
 
+// The reference's optimizer alone: Optimizer::ChooseOptimizer on a text-format config::Optimizer, then `steps` rounds of what
+// EdgeWithWeight does per iteration — NotifyStart (edge_with_weight.cc:108-110) and Optimize (edge_with_weight.cc:96-106) — on
+// one (rows x cols) parameter with the caller's per-step gradients.  params_out receives the parameter after every step.
+void seam_host_sgd(const char* optimizer_text, int rows, int cols, int steps, const float* params_in, const float* grads, float* params_out) {
+  setup_device();
+  config::Optimizer cfg;
+  cfg.ParseFromText(optimizer_text);
+  Optimizer* opt = Optimizer::ChooseOptimizer(cfg);
+  opt->AllocateMemory(rows, cols);
+  Matrix w, g;
+  w.AllocateGPUMemory(rows, cols);
+  g.AllocateGPUMemory(rows, cols);
+  const size_t n = (size_t)rows * cols;
+  memcpy(w.GetHostData(), params_in, sizeof(float) * n);
+  w.CopyToDevice();
+  for (int t = 0; t < steps; ++t) {
+    opt->NotifyStart(w);
+    memcpy(g.GetHostData(), grads + (size_t)t * n, sizeof(float) * n);
+    g.CopyToDevice();
+    opt->Optimize(g, w);
+    w.CopyToHost();
+    memcpy(params_out + (size_t)t * n, w.GetHostData(), sizeof(float) * n);
+  }
+  delete opt;
+}
+
 // The reference's run_grad_check (apps/run_grad_check.cc): GradChecker on the model with its own grad_check flags.
 void seam_host_grad_check(const char* model_pbtxt, int batch_size, const char* output_h5) {
   setup_device();

@@ -42,6 +42,8 @@ class RefHost:
                                              ctypes.c_void_p, ctypes.c_void_p]
         self.lib.seam_host_batch.restype = ctypes.c_long
         self.lib.seam_host_batch.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long]
+        self.lib.seam_host_sgd.restype = None
+        self.lib.seam_host_sgd.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         self.lib.seam_host_grad_check.restype = None
         self.lib.seam_host_grad_check.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
 
@@ -76,6 +78,15 @@ class RefHost:
         n = self.lib.seam_host_batch(str(model).encode(), str(data).encode(), index, x.ctypes.data, x.size, y.ctypes.data, y.size)
         assert n == x.size
         return x, y
+
+    def sgd(self, optimizer_text, params, grads):
+        """The reference's Optimizer (ChooseOptimizer on the text config) stepping one (rows, cols) column-major parameter with
+        grads[t]: the parameter after every step, shape (steps, cols, rows) like `grads`."""
+        steps, cols, rows = grads.shape
+        out = np.zeros_like(grads)
+        p, g = np.ascontiguousarray(params, np.float32), np.ascontiguousarray(grads, np.float32)
+        self.lib.seam_host_sgd(optimizer_text.encode(), rows, cols, steps, p.ctypes.data, g.ctypes.data, out.ctypes.data)
+        return out
 
     def grad_check(self, model, batch, out_h5):
         """apps/run_grad_check.cc: GradChecker::Run writing <edge>_{weights,bias}_{analytical,numerical} to `out_h5`."""

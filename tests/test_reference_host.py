@@ -16,10 +16,12 @@ reference's own 1e-4; this repo's python host, fed the same batches and initial 
 same library; the reference's GradChecker passes on the library; the reference host steps the full AlexNet on it."""
 import ctypes
 import os
+import zlib
 
 import numpy as np
 import pytest
 
+import oracle
 import ref_host
 from golden_cases import rel_err
 from test_net_gpu import small_alexnet
@@ -144,6 +146,70 @@ def test_reference_grad_checker_runs_on_the_reference_cpu_path(cpu_host, tmp_pat
     strict, total, bad = grad_check_verdict(ref_host.read_grad_check(out, GC_EDGES))
     assert total == 2 * len(GC_EDGES) and not bad, bad
     assert strict >= 0.5 * total, (strict, total)
+
+
+class NumpyMatrix:
+    """The Matrix methods SGDOptimizer's unfused path calls (src/optimizer.cc:174-200), on a column-major numpy array, so the
+    python host's optimizer LOGIC — schedules, op order, step counting, Nesterov bookkeeping — runs on the CPU."""
+
+    def __init__(self, a):
+        self.a = np.array(a, np.float32)          # (cols, rows): column-major (rows, cols)
+
+    def GetNumEls(self):
+        return self.a.size
+
+    def Set(self, v):
+        self.a[...] = np.float32(v)
+
+    def Mult(self, v):
+        self.a *= np.float32(v)
+
+    def Add(self, other, mult=1.0):
+        self.a += np.float32(mult) * other.a
+
+    def UpperBoundMod(self, v):
+        np.clip(self.a, -np.float32(v), np.float32(v), out=self.a)
+
+    def NormLimitByAxis(self, axis, val, constraint):
+        assert axis == 1
+        oracle.port.normlimit_rows(self.a, val, constraint)
+
+
+SGD_CONFIGS = {
+    "momentum_l2": "epsilon: 0.05 initial_momentum: 0.9 final_momentum: 0.9 l2_decay: 0.01",
+    "exp_decay_momentum_transition": "epsilon: 0.05 epsilon_decay: EXPONENTIAL epsilon_decay_timescale: 4 initial_momentum: 0.5 "
+                                     "final_momentum: 0.9 momentum_transition_timescale: 3 l2_decay: 0.001",
+    "step_decay_late_start_clip": "epsilon: 0.1 epsilon_decay: EXPONENTIAL_STEP epsilon_decay_timescale: 3 decay_factor: 0.5 "
+                                  "start_optimization_after: 2 gradient_clip: 0.3 final_momentum: 0.8",
+    "linear_decay_norm_limit": "epsilon: 0.2 epsilon_decay: LINEAR epsilon_decay_timescale: 6 minimum_epsilon: 0.02 final_momentum: 0.5 "
+                               "weight_norm_limit: 1.2",
+    "inverse_t_norm_constraint": "epsilon: 0.1 epsilon_decay: INVERSE_T epsilon_decay_timescale: 2 final_momentum: 0.7 "
+                                 "weight_norm_constraint: 1.0",
+    "nesterov": "epsilon: 0.05 initial_momentum: 0.6 final_momentum: 0.9 momentum_transition_timescale: 5 nesterov_momentum: true "
+                "l2_decay: 0.002",
+}
+
+
+@pytest.mark.parametrize("name", sorted(SGD_CONFIGS))
+def test_python_sgd_optimizer_follows_the_reference_optimizer_step_for_step(cpu_host, name):
+    """convnet_amd/optimizer.py (schedules, Nesterov, late start, clip, norm limits) against the reference's compiled
+    SGDOptimizer on its CPU Matrix: same parameter after each of 10 steps."""
+    from convnet_amd import pbtxt
+    from convnet_amd.optimizer import Optimizer
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    rows, cols, steps = 7, 13, 10
+    w0 = rng.standard_normal((cols, rows)).astype(np.float32)
+    grads = rng.standard_normal((steps, cols, rows)).astype(np.float32)
+    want = cpu_host.sgd(SGD_CONFIGS[name], w0, grads)
+
+    opt = Optimizer.ChooseOptimizer(pbtxt.parse(SGD_CONFIGS[name], cls=pbtxt.Optimizer))
+    opt.gradient_history_ = NumpyMatrix(np.zeros_like(w0))
+    w = NumpyMatrix(w0)
+    for t in range(steps):
+        opt.NotifyStart(w)
+        opt.Optimize(NumpyMatrix(grads[t]), w)
+        assert rel_err(w.a, want[t]) < 1e-6, (name, t)
+    assert opt.step_ == steps
 
 
 # ---- GPU: the reference's host on this library ------------------------------------------------------------------------------
