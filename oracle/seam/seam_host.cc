@@ -150,6 +150,7 @@ class SeamNet : public ConvNet {
   Matrix& Params() { return parameters_; }
   Matrix& Grads() { return grad_parameters_; }
   vector<Layer*>& Layers() { return layers_; }
+  vector<Edge*>& Edges() { return edges_; }
   void OneStep(vector<float>& err) { TrainOneBatch(err); }
   float Loss() {   // what GradChecker::GetLoss reads (grad_check.cc:13-16), after the step's own Fprop
     float s = 0.f;
@@ -260,6 +261,25 @@ long seam_host_batch(const char* model_pbtxt, const char* data_pbtxt, int index,
     }
   }
   return nx;
+}
+
+// What the reference's BuildNet / Sort / size inference / AllocateEdgeMemory make of a model: one line per layer in
+// topological (Fprop) order, one line per edge in edge order with its parameter-memory requirement, then the flat buffer size.
+long seam_host_describe(const char* model_pbtxt, const char* data_pbtxt, char* out, long cap) {
+  setup_device();
+  SeamNet net(model_pbtxt);
+  net.SetupDataset(data_pbtxt);
+  net.AllocateMemory(false);
+  std::ostringstream ss;
+  for (Layer* l : net.Layers())
+    ss << "layer " << l->GetName() << " " << l->GetSizeY() << " " << l->GetSizeX() << " " << l->GetNumChannels() << " " << (l->IsInput() ? 1 : 0)
+       << " " << (l->IsOutput() ? 1 : 0) << "\n";
+  for (Edge* e : net.Edges())
+    ss << "edge " << e->GetSource()->GetName() << " " << e->GetDest()->GetName() << " " << e->GetParameterMemoryRequirement() << "\n";
+  ss << "params " << (long)net.Params().GetRows() * net.Params().GetCols() << "\n";
+  const string text = ss.str();
+  if ((long)text.size() + 1 <= cap) memcpy(out, text.c_str(), text.size() + 1);
+  return (long)text.size();
 }
 
 // The reference's optimizer alone: Optimizer::ChooseOptimizer on a text-format config::Optimizer, then `steps` rounds of what

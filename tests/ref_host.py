@@ -42,6 +42,8 @@ class RefHost:
                                              ctypes.c_void_p, ctypes.c_void_p]
         self.lib.seam_host_batch.restype = ctypes.c_long
         self.lib.seam_host_batch.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long]
+        self.lib.seam_host_describe.restype = ctypes.c_long
+        self.lib.seam_host_describe.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_long]
         self.lib.seam_host_sgd.restype = None
         self.lib.seam_host_sgd.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         self.lib.seam_host_grad_check.restype = None
@@ -78,6 +80,23 @@ class RefHost:
         n = self.lib.seam_host_batch(str(model).encode(), str(data).encode(), index, x.ctypes.data, x.size, y.ctypes.data, y.size)
         assert n == x.size
         return x, y
+
+    def describe(self, model, data):
+        """(layers, edges, flat_size) as the reference builds the net: layers = [(name, size_y, size_x, channels, is_input,
+        is_output)] in its topological order, edges = [(source, dest, parameter floats)] in edge order."""
+        buf = ctypes.create_string_buffer(1 << 20)
+        n = self.lib.seam_host_describe(str(model).encode(), str(data).encode(), buf, len(buf))
+        assert 0 < n < len(buf)
+        layers, edges, total = [], [], None
+        for line in buf.value.decode().splitlines():
+            f = line.split()
+            if f[0] == "layer":
+                layers.append((f[1], int(f[2]), int(f[3]), int(f[4]), bool(int(f[5])), bool(int(f[6]))))
+            elif f[0] == "edge":
+                edges.append((f[1], f[2], int(f[3])))
+            else:
+                total = int(f[1])
+        return layers, edges, total
 
     def sgd(self, optimizer_text, params, grads):
         """The reference's Optimizer (ChooseOptimizer on the text config) stepping one (rows, cols) column-major parameter with

@@ -148,6 +148,45 @@ def test_reference_grad_checker_runs_on_the_reference_cpu_path(cpu_host, tmp_pat
     assert strict >= 0.5 * total, (strict, total)
 
 
+def dag_net():
+    """Two conv branches off the input that merge by summation into one layer (a layer with two incoming edges, the
+    add-or-overwrite case of src/layer.cc:307-332), then pool -> fc -> softmax."""
+    from convnet_amd import models
+    L, C, P, F = models._layer, models._conv, models._pool, models._fc
+    s = models._header("dag")
+    s += L("input", 3, size=16)
+    s += L("a", 8, "RECTIFIED_LINEAR") + L("b", 8, "RECTIFIED_LINEAR") + L("merge", 12, "RECTIFIED_LINEAR") + L("pool", 12)
+    s += L("fc", 20, "RECTIFIED_LINEAR") + L("output", 5, "SOFTMAX")
+    s += C("input", "a", 3, 1, 1) + C("input", "b", 5, 1, 2) + C("a", "merge", 3, 1, 1) + C("b", "merge", 1, 1, 0)
+    s += P("merge", "pool", 2, 2, 0) + F("pool", "fc") + F("fc", "output")
+    return s
+
+
+def model_texts():
+    from convnet_amd import models
+    return {"alexnet": models.alexnet(), "alexnet_nin": models.alexnet_nin(), "mnist_conv": models.mnist_conv(), "lenet5": models.lenet5(),
+            "vgg16": models.vgg(), "tiny_alex": small_alexnet(), "dag": dag_net()}
+
+
+@pytest.mark.parametrize("which", ["alexnet", "alexnet_nin", "mnist_conv", "lenet5", "vgg16", "tiny_alex", "dag"])
+def test_python_host_builds_the_same_graph_and_parameter_layout_as_the_reference(cpu_host, tmp_path, which):
+    """BuildNet + Sort + size inference + the flat parameter layout (src/convnet.cc:137-310) of convnet_amd/convnet.py against
+    the reference's compiled ConvNet: same topological layer order, same per-layer sizes, same per-edge parameter counts, same
+    128-float-aligned total.  Runs on the CPU (the python host allocates nothing until AllocateMemory)."""
+    from convnet_amd.convnet import ConvNet
+    text = model_texts()[which]
+    m, d = ref_host.write_configs(tmp_path, text, 2, 1, 1, which)
+    layers, edges, total = cpu_host.describe(m, d)
+
+    net = ConvNet(text)
+    net.SetBatchsize(2)
+    mine_layers = [(l.GetName(), l.GetSizeY(), l.GetSizeX(), l.GetNumChannels(), bool(l.IsInput()), bool(l.IsOutput())) for l in net.layers_]
+    mine_edges = [(e.GetSource().GetName(), e.GetDest().GetName(), e.GetParameterMemoryRequirement()) for e in net.edges_]
+    assert mine_layers == layers
+    assert mine_edges == edges
+    assert sum(((n + 127) // 128) * 128 for _, _, n in mine_edges) == total
+
+
 class NumpyMatrix:
     """The Matrix methods SGDOptimizer's unfused path calls (src/optimizer.cc:174-200), on a column-major numpy array, so the
     python host's optimizer LOGIC — schedules, op order, step counting, Nesterov bookkeeping — runs on the CPU."""
