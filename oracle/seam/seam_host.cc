@@ -263,6 +263,28 @@ long seam_host_batch(const char* model_pbtxt, const char* data_pbtxt, int index,
   return nx;
 }
 
+// `steps` x TrainOneBatch from params_in, then ConvNet::Save(path) (src/convnet.cc:669-684): the reference's own checkpoint
+// writer.  params_out receives the flat parameter buffer that was saved.
+long seam_host_checkpoint(const char* model_pbtxt, const char* data_pbtxt, int steps, const float* params_in, const char* path,
+                          float* params_out, long params_cap) {
+  setup_device();
+  SeamNet net(model_pbtxt);
+  net.SetupDataset(data_pbtxt);
+  net.AllocateMemory(false);
+  Matrix& P = net.Params();
+  const long n = (long)P.GetRows() * P.GetCols();
+  if (params_in) {
+    memcpy(P.GetHostData(), params_in, sizeof(float) * n);
+    P.CopyToDevice();
+  }
+  vector<float> err;
+  for (int i = 0; i < steps; ++i) net.OneStep(err);
+  net.Save(path);
+  P.CopyToHost();
+  if (params_out && n <= params_cap) memcpy(params_out, P.GetHostData(), sizeof(float) * n);
+  return n;
+}
+
 // What the reference's BuildNet / Sort / size inference / AllocateEdgeMemory make of a model: one line per layer in
 // topological (Fprop) order, one line per edge in edge order with its parameter-memory requirement, then the flat buffer size.
 long seam_host_describe(const char* model_pbtxt, const char* data_pbtxt, char* out, long cap) {

@@ -42,6 +42,9 @@ class RefHost:
                                              ctypes.c_void_p, ctypes.c_void_p]
         self.lib.seam_host_batch.restype = ctypes.c_long
         self.lib.seam_host_batch.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long]
+        self.lib.seam_host_checkpoint.restype = ctypes.c_long
+        self.lib.seam_host_checkpoint.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p,
+                                                  ctypes.c_long]
         self.lib.seam_host_describe.restype = ctypes.c_long
         self.lib.seam_host_describe.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_long]
         self.lib.seam_host_sgd.restype = None
@@ -80,6 +83,14 @@ class RefHost:
         n = self.lib.seam_host_batch(str(model).encode(), str(data).encode(), index, x.ctypes.data, x.size, y.ctypes.data, y.size)
         assert n == x.size
         return x, y
+
+    def checkpoint(self, model, data, steps, params, path):
+        """`steps` x TrainOneBatch from `params`, then the reference's ConvNet::Save(path); returns the saved flat parameters."""
+        p = np.ascontiguousarray(params, np.float32)
+        out = np.zeros_like(p)
+        n = self.lib.seam_host_checkpoint(str(model).encode(), str(data).encode(), steps, p.ctypes.data, str(path).encode(), out.ctypes.data, out.size)
+        assert n == out.size
+        return out
 
     def describe(self, model, data):
         """(layers, edges, flat_size) as the reference builds the net: layers = [(name, size_y, size_x, channels, is_input,
@@ -150,3 +161,35 @@ def grad_check_passes(a, n):
         else:
             best = 0.0
     return best < 0.01, best
+
+
+def h5_listing(path):
+    """(dataset names, root attribute names) of an HDF5 file, straight from libhdf5 (no h5py in this image)."""
+    from convnet_amd import hdf5io
+    L = hdf5io._lib()
+    hid = ctypes.c_int64
+    for name, res, args in (("H5Gget_num_objs", ctypes.c_int, [hid, ctypes.POINTER(ctypes.c_uint64)]),
+                            ("H5Lget_name_by_idx", ctypes.c_ssize_t, [hid, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_char_p,
+                                                                      ctypes.c_size_t, hid]),
+                            ("H5Aget_num_attrs", ctypes.c_int, [hid]),
+                            ("H5Aget_name_by_idx", ctypes.c_ssize_t, [hid, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_char_p,
+                                                                      ctypes.c_size_t, hid])):
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    with hdf5io.File(str(path), "r") as f:
+        n = ctypes.c_uint64(0)
+        assert L.H5Gget_num_objs(f.id, ctypes.byref(n)) >= 0
+        buf = ctypes.create_string_buffer(512)
+        names, attrs = [], []
+        for i in range(n.value):
+            assert L.H5Lget_name_by_idx(f.id, b".", 0, 0, i, buf, len(buf), 0) >= 0
+            names.append(buf.value.decode())
+        L.H5Gopen2.restype, L.H5Gopen2.argtypes = hid, [hid, ctypes.c_char_p, hid]
+        L.H5Gclose.restype, L.H5Gclose.argtypes = ctypes.c_int, [hid]
+        root = L.H5Gopen2(f.id, b"/", 0)       # attributes written "on the file" live on its root group
+        assert root >= 0
+        for i in range(L.H5Aget_num_attrs(root)):
+            assert L.H5Aget_name_by_idx(root, b".", 0, 0, i, buf, len(buf), 0) >= 0
+            attrs.append(buf.value.decode())
+        L.H5Gclose(root)
+    return sorted(names), sorted(attrs)

@@ -187,6 +187,54 @@ def test_python_host_builds_the_same_graph_and_parameter_layout_as_the_reference
     assert sum(((n + 127) // 128) * 128 for _, _, n in mine_edges) == total
 
 
+def test_reference_written_checkpoint_has_exactly_what_the_python_host_reads_and_writes(cpu_host, golden, tmp_path):
+    """A checkpoint written by the reference's own ConvNet::Save after 3 training steps: (1) its dataset / attribute names are
+    exactly the ones convnet_amd's Save path emits (captured with recording stand-ins, no device needed), (2) every dataset
+    holds the bytes of the corresponding slice of the reference's flat parameter buffer in the layout the python host assumes
+    (weight (F x fan_in) column-major, then the bias), and (3) the optimizer step attributes carry the step count."""
+    from convnet_amd import hdf5io
+    from convnet_amd.convnet import ConvNet
+    text = small_alexnet()
+    m, d = ref_host.write_configs(tmp_path, text, golden["batch"], golden["num_batches"], golden["seed"])
+    path = os.path.join(str(tmp_path), "ref_ckpt.h5")
+    saved = cpu_host.checkpoint(m, d, golden["steps"], golden["p0"], path)
+    assert_flat_close(saved, golden["p3"], text, 1e-6, "saved parameters")
+    names, attrs = ref_host.h5_listing(path)
+
+    class Rec:                      # stands in for a Matrix and for hdf5io.File: records what Save would write
+        def __init__(self, log):
+            self.log = log
+
+        def WriteHDF5(self, file, name):
+            self.log.append(("dataset", name))
+
+        def WriteHDF5IntAttr(self, name, val):
+            self.log.append(("attr", name))
+
+        def GetNumEls(self):
+            return 1
+
+    log = []
+    net = ConvNet(text)
+    for e in net.edges_:
+        if hasattr(e, "weight_optimizer_"):
+            e.weights_, e.bias_ = Rec(log), Rec(log)
+            e.weight_optimizer_.gradient_history_, e.bias_optimizer_.gradient_history_ = Rec(log), Rec(log)
+        e.SaveParameters(Rec(log))
+    assert sorted(n for k, n in log if k == "dataset") == names
+    assert sorted([n for k, n in log if k == "attr"] + ["__current_iter__", "__lr_reduce_counter__"]) == attrs
+
+    with hdf5io.File(path, "r") as f:
+        for name, off, n in slices(saved.size, text):
+            rows, cols = f.ReadHDF5Shape(name + ":weight")          # (F, fan_in)
+            w = f.ReadHDF5CPU(rows * cols, name + ":weight")
+            b = f.ReadHDF5CPU(n - rows * cols, name + ":bias")
+            assert np.array_equal(w, saved[off:off + rows * cols]) and np.array_equal(b, saved[off + rows * cols:off + n]), name
+            assert f.ReadHDF5Shape(name + ":weight_gradient_history") == (rows, cols)
+            assert f.ReadHDF5IntAttr(name + ":weight_step", -1) == golden["steps"] == f.ReadHDF5IntAttr(name + ":bias_step", -1)
+        assert f.ReadHDF5IntAttr("__current_iter__", -1) == 0 and f.ReadHDF5IntAttr("__lr_reduce_counter__", -1) == 0
+
+
 class NumpyMatrix:
     """The Matrix methods SGDOptimizer's unfused path calls (src/optimizer.cc:174-200), on a column-major numpy array, so the
     python host's optimizer LOGIC — schedules, op order, step counting, Nesterov bookkeeping — runs on the CPU."""
