@@ -151,6 +151,7 @@ class SeamNet : public ConvNet {
   Matrix& Grads() { return grad_parameters_; }
   vector<Layer*>& Layers() { return layers_; }
   vector<Edge*>& Edges() { return edges_; }
+  bool ReduceLr(const vector<float>& v) { return CheckReduceLearningRate(v); }
   void OneStep(vector<float>& err) { TrainOneBatch(err); }
   float Loss() {   // what GradChecker::GetLoss reads (grad_check.cc:13-16), after the step's own Fprop
     float s = 0.f;
@@ -283,6 +284,18 @@ long seam_host_checkpoint(const char* model_pbtxt, const char* data_pbtxt, int s
   P.CopyToHost();
   if (params_out && n <= params_cap) memcpy(params_out, P.GetHostData(), sizeof(float) * n);
   return n;
+}
+
+// ConvNet::CheckReduceLearningRate (src/convnet.cc:788-818) on every prefix of a validation-error history: out[i] = decision
+// after i+1 validations, with the model's reduce_lr_num_steps / reduce_lr_threshold / smaller_is_better.
+void seam_host_reduce_lr(const char* model_pbtxt, const float* errors, int n, int* out) {
+  setup_device();
+  SeamNet net(model_pbtxt);
+  vector<float> hist;
+  for (int i = 0; i < n; ++i) {
+    hist.push_back(errors[i]);
+    out[i] = net.ReduceLr(hist) ? 1 : 0;
+  }
 }
 
 // What the reference's BuildNet / Sort / size inference / AllocateEdgeMemory make of a model: one line per layer in

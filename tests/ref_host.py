@@ -45,6 +45,8 @@ class RefHost:
         self.lib.seam_host_checkpoint.restype = ctypes.c_long
         self.lib.seam_host_checkpoint.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p,
                                                   ctypes.c_long]
+        self.lib.seam_host_reduce_lr.restype = None
+        self.lib.seam_host_reduce_lr.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         self.lib.seam_host_describe.restype = ctypes.c_long
         self.lib.seam_host_describe.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_long]
         self.lib.seam_host_sgd.restype = None
@@ -91,6 +93,13 @@ class RefHost:
         n = self.lib.seam_host_checkpoint(str(model).encode(), str(data).encode(), steps, p.ctypes.data, str(path).encode(), out.ctypes.data, out.size)
         assert n == out.size
         return out
+
+    def reduce_lr_decisions(self, model, errors):
+        """ConvNet::CheckReduceLearningRate after each validation of the history `errors`."""
+        e = np.ascontiguousarray(errors, np.float32)
+        out = np.zeros(e.size, np.int32)
+        self.lib.seam_host_reduce_lr(str(model).encode(), e.ctypes.data, e.size, out.ctypes.data)
+        return out.astype(bool)
 
     def describe(self, model, data):
         """(layers, edges, flat_size) as the reference builds the net: layers = [(name, size_y, size_x, channels, is_input,

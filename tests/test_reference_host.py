@@ -235,6 +235,26 @@ def test_reference_written_checkpoint_has_exactly_what_the_python_host_reads_and
         assert f.ReadHDF5IntAttr("__current_iter__", -1) == 0 and f.ReadHDF5IntAttr("__lr_reduce_counter__", -1) == 0
 
 
+@pytest.mark.parametrize("num_steps,smaller,threshold", [(2, True, 0.0), (3, True, 0.01), (4, False, 0.005), (6, True, 0.002), (5, False, 0.0)])
+def test_python_lr_reduce_rule_equals_the_reference_rule(cpu_host, tmp_path, num_steps, smaller, threshold):
+    """TrainLoopMixin.CheckReduceLearningRate (convnet_amd/trainer.py) against the compiled ConvNet::CheckReduceLearningRate on a
+    noisy plateauing validation curve, decision by decision."""
+    from convnet_amd.convnet import ConvNet
+    from convnet_amd import models
+    text = models.lenet5().replace("max_iter: 10000000", f"max_iter: 10000000\nreduce_lr_num_steps: {num_steps}\n"
+                                   f"reduce_lr_threshold: {threshold}\nsmaller_is_better: {'true' if smaller else 'false'}")
+    m, _ = ref_host.write_configs(tmp_path, text, 2, 1, 1, "lr")
+    rng = np.random.default_rng(num_steps)
+    curve = (0.6 * np.exp(-np.arange(40) / 6.0) + 0.2 + 0.01 * rng.standard_normal(40)).astype(np.float32)
+    if not smaller:
+        curve = (1.0 - curve).astype(np.float32)
+    want = cpu_host.reduce_lr_decisions(m, curve)
+    net = ConvNet(text)
+    got = [net.CheckReduceLearningRate([float(v) for v in curve[:i + 1]]) for i in range(curve.size)]
+    assert list(want) == got
+    assert want.any() and not want.all()
+
+
 class NumpyMatrix:
     """The Matrix methods SGDOptimizer's unfused path calls (src/optimizer.cc:174-200), on a column-major numpy array, so the
     python host's optimizer LOGIC — schedules, op order, step counting, Nesterov bookkeeping — runs on the CPU."""
