@@ -265,6 +265,18 @@ class NumpyMatrix:
     def GetNumEls(self):
         return self.a.size
 
+    def GetRows(self):
+        return self.a.shape[1]
+
+    def GetCols(self):
+        return self.a.shape[0]
+
+    def FillWithRand(self):
+        self.a[...] = np.random.default_rng(self.a.size).random(self.a.shape, dtype=np.float32)
+
+    def FillWithRandn(self):
+        self.a[...] = np.random.default_rng(self.a.size).standard_normal(self.a.shape, dtype=np.float32)
+
     def Set(self, v):
         self.a[...] = np.float32(v)
 
@@ -272,7 +284,10 @@ class NumpyMatrix:
         self.a *= np.float32(v)
 
     def Add(self, other, mult=1.0):
-        self.a += np.float32(mult) * other.a
+        if isinstance(other, NumpyMatrix):
+            self.a += np.float32(mult) * other.a
+        else:
+            self.a += np.float32(other)
 
     def UpperBoundMod(self, v):
         np.clip(self.a, -np.float32(v), np.float32(v), out=self.a)
@@ -280,6 +295,35 @@ class NumpyMatrix:
     def NormLimitByAxis(self, axis, val, constraint):
         assert axis == 1
         oracle.port.normlimit_rows(self.a, val, constraint)
+
+
+@pytest.mark.parametrize("init", ["DENSE_GAUSSIAN", "DENSE_GAUSSIAN_SQRT_FAN_IN", "DENSE_UNIFORM", "DENSE_UNIFORM_SQRT_FAN_IN", "CONSTANT"])
+def test_python_weight_initialisation_rules_match_the_reference_statistically(cpu_host, tmp_path, init):
+    """EdgeWithWeight.Initialize (convnet_amd/edge.py) against the compiled reference's initial parameter buffer: different
+    random streams, so the comparison is on what the rule fixes — the spread of every weight tensor (and the bound of the uniform
+    rules), the exact constant, the exact bias."""
+    from convnet_amd.convnet import ConvNet
+    text = small_alexnet().replace("initialization: DENSE_UNIFORM_SQRT_FAN_IN", f"initialization: {init}").replace("init_wt: 1.0", "init_wt: 0.7")
+    assert init in text and "init_wt: 0.7" in text
+    m, d = ref_host.write_configs(tmp_path, text, 2, 1, 1, "init")
+    p0 = cpu_host.init_params(m, d)
+    net = ConvNet(text)
+    by_name = {f"{e.GetSource().GetName()}:{e.GetDest().GetName()}": e for e in net.edges_}
+    for name, off, n in slices(p0.size, text):
+        e = by_name[name]
+        F = e.GetDest().GetNumChannels()
+        fan_in = n // F - 1
+        e.weights_, e.bias_ = NumpyMatrix(np.zeros((fan_in, F), np.float32)), NumpyMatrix(np.zeros((1, F), np.float32))
+        e.Initialize()
+        ref_w, ref_b = p0[off:off + F * fan_in], p0[off + F * fan_in:off + n]
+        assert np.array_equal(e.bias_.a.reshape(-1), ref_b), name
+        if init == "CONSTANT":
+            assert np.array_equal(e.weights_.a.reshape(-1), ref_w), name
+            continue
+        assert abs(e.weights_.a.mean() - ref_w.mean()) < 0.15 * ref_w.std(), name
+        assert abs(e.weights_.a.std() / ref_w.std() - 1.0) < 0.08, (name, e.weights_.a.std(), ref_w.std())
+        if "UNIFORM" in init:
+            assert abs(np.abs(e.weights_.a).max() / np.abs(ref_w).max() - 1.0) < 0.03, name
 
 
 SGD_CONFIGS = {
