@@ -464,7 +464,6 @@ def test_python_host_equals_the_reference_host_on_the_same_library(hip_host, gol
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason="written at the end of round 1 with no GPU budget left: never run on a GPU yet; XPASS = confirmed")
 @pytest.mark.parametrize("fused", [False, True], ids=["unfused", "fused"])
 def test_python_host_trains_the_merging_dag_like_the_reference_cpu_host(golden_dag, fused):
     """A layer with two incoming edges (add-or-overwrite on Fprop, two ComputeDown contributions into the input... on Bprop,
