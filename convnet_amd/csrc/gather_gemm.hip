@@ -1226,6 +1226,8 @@ ConvGeo conv_geo(const Shape4D* img, const Shape4D* flt, const Shape4D* out, con
   CHIP_REQUIRE(mf->size[0] == g.F && mf->size[1] == g.Ky * g.Kx * g.C);
   CHIP_REQUIRE(g.My == (g.H - 2 * g.py - g.Ky) / g.sy + 1 && g.Mx == (g.W - 2 * g.px - g.Kx) / g.sx + 1);
   CHIP_REQUIRE(d.kernel_size_t <= 1);
+  // the kernels index activations with 32-bit element offsets: refuse loudly instead of wrapping (2^31 floats = 8.6 GB per tensor)
+  CHIP_REQUIRE((size_t)g.N * g.H * g.W * g.C < (1ull << 31) && (size_t)g.N * g.My * g.Mx * g.F < (1ull << 31));
   return g;
 }
 
