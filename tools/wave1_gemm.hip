@@ -6,7 +6,7 @@
 // global_load_lds (16 B per lane, 8 per thread per chunk, one issued per k-step); fragments read one k-step ahead with two
 // ds_read_b128 per k-step (rows/cols permuted so that a lane's four tiles are contiguous); one barrier per chunk.
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/wave1_gemm tools/wave1_gemm.hip ; run on the GPU box:
-//     tools/wave1_gemm [M N K]      (defaults 4096 4096 4096; prints TFLOP/s and the max error against a sampled fp64 check)
+//     tools/wave1_gemm [M N K [variant]] | [variant]     (defaults 4096 4096 4096, variant 2; prints TFLOP/s and the max error against a sampled fp64 check)
 // Status (end of round 1): first untuned version, run once on an MI355X: 4096^3 in 1.144 ms = 120.2 TFLOP/s, results correct
 // (max rel err 4e-5 on 64 fp64-checked samples).  See NOTES.md for what to try next.
 #include <hip/hip_runtime.h>
@@ -23,6 +23,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int BK = 16, TM = 256, TN = 256, STAGES = 3;
 constexpr int A_STAGE = BK * TM, B_STAGE = BK * TN, STAGE = A_STAGE + B_STAGE;   // floats
 
+// VARIANT 0: staging / barrier guarded by wave-uniform branches (the version measured at 120.2 TFLOP/s).  The branches split
+//            every k-step into its own basic block and the compiler then waits lgkmcnt(0) — i.e. also for the two fragment
+//            reads it has just issued — in every second k-step.
+// VARIANT 1: branch-free chunk body: past the end of K the staging re-reads the last chunk into a stage nobody reads again, the
+//            barrier and the look-ahead fragment read run unconditionally; one basic block per chunk, exact waitcnts.
+template <int VARIANT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 wave1_gemm(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -86,6 +92,7 @@ wave1_gemm(const float* __restrict__ A, const float* __restrict__ B, float* __re
   f32x4 fa, fb, na, nb;
   frag(0, 0, fa, fb);
 
+  if constexpr (VARIANT == 0) {
   for (int c = 0; c < nchunks; ++c) {
     const int st = c % STAGES, st_next = (c + 1) % STAGES, st_fill = (c + 2) % STAGES;
     const bool fill = c + 2 < nchunks;
@@ -113,6 +120,69 @@ wave1_gemm(const float* __restrict__ A, const float* __restrict__ B, float* __re
       fb = nb;
     }
     if (fill) advance();
+  }
+  } else if constexpr (VARIANT == 1) {
+  int st = 0;   // stage of chunk c; chunk c+1 is in st+1, chunk c+2 is being filled into st+2 (mod 3)
+  for (int c = 0; c < nchunks; ++c) {
+    const int st_next = st == STAGES - 1 ? 0 : st + 1, st_fill = st_next == STAGES - 1 ? 0 : st_next + 1;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks < 7) {
+        frag(st, ks + 1, na, nb);
+      } else {
+        __builtin_amdgcn_s_waitcnt(0x0077);   // vmcnt(7): chunk c+1 complete (7 pieces of chunk c+2 are younger); lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        frag(st_next, 0, na, nb);             // past the last chunk: reads a stale stage, never used
+      }
+      stage_piece(ks, st_fill);               // past the end of K: re-reads the last chunk into a stage nobody reads again
+      __builtin_amdgcn_sched_barrier(0);      // keep the look-ahead reads ABOVE this step's MFMAs (the scheduler sinks them to their use)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      fa = na;
+      fb = nb;
+    }
+    if (c + 3 < nchunks) advance();           // the source pointers stop at the last chunk
+    st = st_next;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);         // the trailing dummy loads must land before the LDS is released
+  } else {
+  // VARIANT 2: as 1, but the look-ahead fragment reads and the staging load sit in the MIDDLE of the step's 16 MFMAs.  The
+  // compiler waits lgkmcnt(0) before the first use of a fragment whatever else is in flight (it treats the LDS-DMA loads as
+  // LDS traffic); with the reads issued 8 MFMAs = 512 pipe cycles before that wait, it never finds anything outstanding.
+  int st = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const int st_next = st == STAGES - 1 ? 0 : st + 1, st_fill = st_next == STAGES - 1 ? 0 : st_next + 1;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks < 7) {
+        frag(st, ks + 1, na, nb);
+      } else {
+        __builtin_amdgcn_s_waitcnt(0x0077);   // vmcnt(7): chunk c+1 complete; lgkmcnt(0): this wave is done reading stage st
+        __builtin_amdgcn_s_barrier();
+        frag(st_next, 0, na, nb);
+      }
+      stage_piece(ks, st_fill);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rt = 2; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rt], fb[ct], acc[rt][ct], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      fa = na;
+      fb = nb;
+    }
+    if (c + 3 < nchunks) advance();
+    st = st_next;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);
   }
 
   // epilogue: logical row m of row tile rt = physical row 4m + rt; logical col n = lane%32 of col tile ct = physical col 4n + ct
@@ -142,15 +212,17 @@ int main(int argc, char** argv) {
   hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
   const size_t lds = sizeof(float) * STAGES * STAGE;
-  hipFuncSetAttribute((const void*)wave1_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int variant = argc > 4 ? atoi(argv[4]) : (argc == 2 ? atoi(argv[1]) : 2);
+  auto kernel = variant == 0 ? wave1_gemm<0> : variant == 1 ? wave1_gemm<1> : wave1_gemm<2>;
+  hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   dim3 grid(N / TN, M / TM), block(256);
-  hipLaunchKernelGGL(wave1_gemm, grid, block, lds, 0, A, B, C, M, N, K);
+  hipLaunchKernelGGL(kernel, grid, block, lds, 0, A, B, C, M, N, K);
   if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   const int reps = 10;
   hipEventRecord(e0);
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(wave1_gemm, grid, block, lds, 0, A, B, C, M, N, K);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kernel, grid, block, lds, 0, A, B, C, M, N, K);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -164,7 +236,7 @@ int main(int argc, char** argv) {
     for (int k = 0; k < K; ++k) ref += (double)hA[(size_t)k * M + r] * hB[(size_t)k * N + n];
     worst = fmax(worst, fabs(ref - hC[(size_t)r * N + n]) / (fabs(ref) + 1e-3));
   }
-  printf("wave1_gemm %dx%dx%d: %.3f ms  %.1f TFLOP/s  blocks=%d  max rel err (64 samples) %.2e\n", M, N, K, ms,
+  printf("wave1_gemm<%d> %dx%dx%d: %.3f ms  %.1f TFLOP/s  blocks=%d  max rel err (64 samples) %.2e\n", variant, M, N, K, ms,
          2.0 * M * N * (double)K / ms * 1e-9, grid.x * grid.y, worst);
   return worst < 1e-3 ? 0 : 1;
 }
