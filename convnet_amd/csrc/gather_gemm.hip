@@ -183,8 +183,13 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT]
 // O3 = the 3-blocks-per-CU build (launch bound 3 waves/SIMD + the k-row-major B stage that makes it fit): chosen by the
 // host only for launches with enough tiles to fill >= 2 rounds of 768 slots, where it gains 2-6 %; on ~512-tile launches
 // the blocks spread 3/1 over the CUs and it loses, so the 2-block build stays the default.
-template <int WR, int WC, int MT, int CW, bool A_KCONTIG, bool VEC, bool O3 = false>
+// ST = LDS stages.  2: double buffer (the measured default).  3 (EXPERIMENT, selected only by CONVNET_GG_STAGES3=1, r-contiguous
+// vector build): the loads of chunk c+2 are issued at the start of chunk c, so each load has two MFMA phases to land and the
+// chunk-closing wait is vmcnt(loads of one chunk) instead of vmcnt(0); the first fragments of chunk c+1 are read right after
+// that barrier, ahead of the last k-step's MFMAs, instead of in front of the first MFMA of chunk c+1 (NOTES.md).
+template <int WR, int WC, int MT, int CW, bool A_KCONTIG, bool VEC, bool O3 = false, int ST = 2>
 __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGParams pin, const GGClassTable ct) {
+  static_assert(ST == 2 || (ST == 3 && VEC && !A_KCONTIG && !O3), "the 3-stage ring is a variant of the r-contiguous vector build");
   constexpr int NT = WR * WC * 64;
   constexpr int NTC = CW / 32, CW4 = CW / 4;
   using fvec = __attribute__((ext_vector_type(NTC))) float;
@@ -195,8 +200,8 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
   constexpr int NA = ((A_KCONTIG ? ROWS * (BK / 4) : BK * (ROWS / 4)) + NT - 1) / NT;
   constexpr int NB = (WC * BK * CW4 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                 // [2][A_STAGE]
-  float* Bs = smem + 2 * A_STAGE;   // [2][B_STAGE]
+  float* As = smem;                  // [ST][A_STAGE]
+  float* Bs = smem + ST * A_STAGE;   // [ST][B_STAGE]
 
   // fields a stride class overrides live in scalars; everything else is read from the kernarg struct in place
   const GGParams& p = pin;
@@ -496,6 +501,65 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
   constexpr bool SPREAD = false && GLDS_A && GLDS_B;
   constexpr bool PRIO = true;
   constexpr int NP = NA + NB, PPS = (NP + BK / 2 - 1) / (BK / 2);
+  if constexpr (ST == 3) {
+    // loads every wave of the block issues per chunk (slots whose 256-lane group lies wholly inside the tile): the chunk-closing
+    // wait may leave that many (the youngest = chunk c+2) outstanding; a wave that issued more waits for a few of them too
+    constexpr int A_ALL = (BK * (ROWS / 4)) / NT < NA ? (BK * (ROWS / 4)) / NT : NA;
+    constexpr int B_ALL = (WC * BK * CW4) / NT < NB ? (WC * BK * CW4) / NT : NB;
+    constexpr int NWAIT = A_ALL + B_ALL;
+    static_assert(NWAIT >= 1 && NWAIT < 64, "vmcnt immediate");
+    constexpr int WAIT_NEXT = (NWAIT & 15) | ((NWAIT >> 4) << 14) | 0x0070;   // vmcnt(NWAIT) expcnt(7) lgkmcnt(0)
+    if (nchunks > 1) fetch(kbeg + BK, 1);
+    float a[2][MT];
+    fvec b4[2];
+    {
+      const float* ar = As + wr * MT * 32 + li;
+      const float* bs = Bs + (KM ? wc * CW : wc * BK * CW) + NTC * li;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) a[0][t] = ar[lh * ROWS + t * 32];
+      b4[0] = *reinterpret_cast<const fvec*>(bs + lh * BROW);
+    }
+    int buf = 0;
+    for (int c = 0; c < nchunks; ++c) {
+      const int nbuf = buf == 2 ? 0 : buf + 1, fbuf = nbuf == 2 ? 0 : nbuf + 1;
+      const bool more = c + 1 < nchunks, fill = c + 2 < nchunks;
+      if (fill) fetch(kbeg + (c + 2) * BK, fbuf);
+      const float* ar = As + buf * A_STAGE + wr * MT * 32 + li;
+      const float* bs = Bs + buf * B_STAGE + (KM ? wc * CW : wc * BK * CW) + NTC * li;
+      const float* arn = As + nbuf * A_STAGE + wr * MT * 32 + li;
+      const float* bsn = Bs + nbuf * B_STAGE + (KM ? wc * CW : wc * BK * CW) + NTC * li;
+      if (PRIO) __builtin_amdgcn_s_setprio(2);
+      static_for<0, BK / 2>([&](auto KK) __attribute__((always_inline)) {
+        constexpr int kk = decltype(KK)::value;
+        constexpr int cur = kk & 1, nxt = cur ^ 1;
+        if constexpr (kk + 1 < BK / 2) {
+          const int krow = 2 * (kk + 1) + lh;
+#pragma unroll
+          for (int t = 0; t < MT; ++t) a[nxt][t] = ar[krow * ROWS + t * 32];
+          b4[nxt] = *reinterpret_cast<const fvec*>(bs + krow * BROW);
+        } else {
+          // hand-over: chunk c+1 has landed (everything older than this wave's chunk-c+2 loads), every wave has read its
+          // last fragments of this stage (lgkmcnt(0)) so the stage may be refilled next chunk; then the first fragments of
+          // chunk c+1, covered by this k-step's MFMAs
+          if (more) {
+            if (fill) __builtin_amdgcn_s_waitcnt(WAIT_NEXT); else __builtin_amdgcn_s_waitcnt(0x0070);
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a[nxt][t] = arn[lh * ROWS + t * 32];
+            b4[nxt] = *reinterpret_cast<const fvec*>(bsn + lh * BROW);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int u = 0; u < NTC; ++u)
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], b4[cur][u], acc[t][u], 0, 0, 0);
+      });
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
+      buf = nbuf;
+    }
+  } else {
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
     const bool more = c + 1 < nchunks;
@@ -564,6 +628,7 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
     }
     if (c + 1 < nchunks) stash(buf ^ 1);
     __syncthreads();
+  }
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------
@@ -1073,7 +1138,18 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
         hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, true, true>), grid, block, lds, stream(), p, kNoClasses);
       }
     }
-    if (o3) {
+    // EXPERIMENT, off unless CONVNET_GG_STAGES3=1: three LDS stages for the two r-contiguous vector builds AlexNet uses
+    static const bool stages3 = [] { const char* e = getenv("CONVNET_GG_STAGES3"); return e && *e && *e != '0'; }();
+    bool done3 = false;
+    if constexpr (!AK && ((WR == 2 && WC == 2 && MT == 2 && CW == 128) || (WR == 1 && WC == 4 && MT == 3 && CW == 64))) {
+      if (stages3 && vec && !o3) {
+        const size_t lds3 = sizeof(float) * 3 * (A_STAGE + B_STAGE);
+        allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, true, false, 3>, lds3);
+        hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, true, false, 3>), grid, block, lds3, stream(), p, kNoClasses);
+        done3 = true;
+      }
+    }
+    if (o3 || done3) {
     } else if (vec) {
       allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, true>, lds);
       hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, true>), grid, block, lds, stream(), p, kNoClasses);
