@@ -532,6 +532,15 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
       static_for<0, BK / 2>([&](auto KK) __attribute__((always_inline)) {
         constexpr int kk = decltype(KK)::value;
         constexpr int cur = kk & 1, nxt = cur ^ 1;
+        constexpr int HALF = (MT + 1) / 2;   // row tiles issued before the look-ahead reads
+        // first part of this k-step's MFMAs, THEN the look-ahead reads: the compiler covers a fragment with lgkmcnt(0) whatever
+        // else is in flight, so reads issued directly above a wait stall it; issued here they have the second part to land
+#pragma unroll
+        for (int t = 0; t < HALF; ++t)
+#pragma unroll
+          for (int u = 0; u < NTC; ++u)
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], b4[cur][u], acc[t][u], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (kk + 1 < BK / 2) {
           const int krow = 2 * (kk + 1) + lh;
 #pragma unroll
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
         } else {
           // hand-over: chunk c+1 has landed (everything older than this wave's chunk-c+2 loads), every wave has read its
           // last fragments of this stage (lgkmcnt(0)) so the stage may be refilled next chunk; then the first fragments of
-          // chunk c+1, covered by this k-step's MFMAs
+          // chunk c+1, covered by the rest of this k-step's MFMAs and the next chunk's staging block
           if (more) {
             if (fill) __builtin_amdgcn_s_waitcnt(WAIT_NEXT); else __builtin_amdgcn_s_waitcnt(0x0070);
             __builtin_amdgcn_s_barrier();
@@ -551,10 +560,11 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
+        for (int t = HALF; t < MT; ++t)
 #pragma unroll
           for (int u = 0; u < NTC; ++u)
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], b4[cur][u], acc[t][u], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       });
       if (PRIO) __builtin_amdgcn_s_setprio(0);
       buf = nbuf;
