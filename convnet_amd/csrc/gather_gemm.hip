@@ -1057,7 +1057,18 @@ void gg_launch_classes(GGParams& p, GGClassTable& ct, bool vec) {
   static const std::string kname = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ",rc>";
   KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0);
   dim3 grid(end), block(WR * WC * 64);
-  if (vec) {
+  static const bool stages3 = [] { const char* e = getenv("CONVNET_GG_STAGES3"); return e && *e && *e != '0'; }();   // EXPERIMENT, see gg_kernel
+  bool done3 = false;
+  if constexpr ((WR == 2 && WC == 2 && MT == 2 && CW == 128) || (WR == 1 && WC == 4 && MT == 3 && CW == 64)) {
+    if (stages3 && vec) {
+      const size_t lds3 = lds / 2 * 3;
+      allow_big_lds(gg_kernel<WR, WC, MT, CW, false, true, false, 3>, lds3);
+      hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, false, true, false, 3>), grid, block, lds3, stream(), p, ct);
+      done3 = true;
+    }
+  }
+  if (done3) {
+  } else if (vec) {
     allow_big_lds(gg_kernel<WR, WC, MT, CW, false, true>, lds);
     hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, false, true>), grid, block, lds, stream(), p, ct);
   } else {
