@@ -742,7 +742,10 @@ constexpr int WG_PITCH = WG_NB + 4;  // conflict-free ds_read_b128 across rows
 // tile; same FLOP/clk).  The 16-wide tiles let a 160 x 96 problem (conv1: 147 taps x 96 filters) split evenly
 // over 2x2 waves (80 x 48 each), which no arrangement of 32-wide tiles can: the 5-wave 32x32 config ran at 70
 // TFLOP/s with 10 waves on 4 SIMDs.
-template <int WM, int WN, int MT, int NTL, bool VEC, int TS>
+// PF (EXPERIMENT, selected only by CONVNET_WG_PREFETCH=1): explicit double-buffered fragment registers with the next group's
+// ds_reads issued between the two halves of the current group's MFMAs.  In the default build the compiler overlaps a little
+// by itself but waits lgkmcnt(0) directly under the reads it has just issued, once per 16 MFMAs (NOTES.md).
+template <int WM, int WN, int MT, int NTL, bool VEC, int TS, bool PF = false>
 __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int KT = WM * MT * TS;   // k-columns (D rows) per block
@@ -934,6 +937,46 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
     if (c + 1 < cend) fetch(c + 1, buf ^ 1);
     const float* ar = As + buf * A_STAGE + (wm * MT * TS + li) * PITCH;
     const float* br = Bs + buf * B_STAGE + (wn * NTL * TS + li) * PITCH;
+    if constexpr (PF) {
+      constexpr int Q = WG_NB / (4 * LH);
+      f32x4 a4[2][MT], b4[2][NTL];
+      {
+        const int piece = 4 * (lh ^ swz);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a4[0][t] = ld4(ar + t * TS * PITCH + piece);
+#pragma unroll
+        for (int u = 0; u < NTL; ++u) b4[0][u] = ld4(br + u * TS * PITCH + piece);
+      }
+      static_for<0, Q>([&](auto QQ) __attribute__((always_inline)) {
+        constexpr int q = decltype(QQ)::value;
+        constexpr int cur = q & 1, nxt = cur ^ 1;
+        auto mfmas = [&](int e) __attribute__((always_inline)) {
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < NTL; ++u) {
+              if constexpr (TS == 32)
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[cur][t][e], b4[cur][u][e], acc[t][u], 0, 0, 0);
+              else
+                acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[cur][t][e], b4[cur][u][e], acc[t][u], 0, 0, 0);
+            }
+        };
+        mfmas(0);
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (q + 1 < Q) {
+          const int piece = 4 * ((LH * (q + 1) + lh) ^ swz);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) a4[nxt][t] = ld4(ar + t * TS * PITCH + piece);
+#pragma unroll
+          for (int u = 0; u < NTL; ++u) b4[nxt][u] = ld4(br + u * TS * PITCH + piece);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(2);
+        mfmas(3);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    } else
 #pragma unroll
     for (int q = 0; q < WG_NB / (4 * LH); ++q) {   // one b128 per lane = 4*LH images of the stage
       const int piece = 4 * ((LH * q + lh) ^ swz);
@@ -1256,8 +1299,14 @@ void wg_launch_cfg(WGParams& p, bool vec) {
   {
     KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0);
     if (vec) {
-      allow_big_lds(wg_kernel<WM, WN, MT, NTL, true, TS>, lds);
-      hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, true, TS>), grid, block, lds, stream(), p);
+      static const bool prefetch = [] { const char* e = getenv("CONVNET_WG_PREFETCH"); return e && *e && *e != '0'; }();   // EXPERIMENT, see wg_kernel
+      if (prefetch) {
+        allow_big_lds(wg_kernel<WM, WN, MT, NTL, true, TS, true>, lds);
+        hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, true, TS, true>), grid, block, lds, stream(), p);
+      } else {
+        allow_big_lds(wg_kernel<WM, WN, MT, NTL, true, TS>, lds);
+        hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, true, TS>), grid, block, lds, stream(), p);
+      }
     } else {
       allow_big_lds(wg_kernel<WM, WN, MT, NTL, false, TS>, lds);
       hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, false, TS>), grid, block, lds, stream(), p);

@@ -17,12 +17,20 @@ timeout 60 python tools/layer_bench.py > "$O/layer_default.log" 2>&1
 CONVNET_GG_STAGES3=1 timeout 60 python tools/layer_bench.py > "$O/layer_stages3.log" 2>&1
 paste <(grep gg_kernel "$O/layer_default.log") <(grep gg_kernel "$O/layer_stages3.log" | awk '{print $(NF-1), $NF}') | head -20
 
+echo "== 2b. dormant wgrad fragment prefetch (CONVNET_WG_PREFETCH=1): correctness, then speed per layer"
+CONVNET_WG_PREFETCH=1 timeout 120 python -m pytest tests/test_hip_parity.py tests/test_net_gpu.py -x -q -m gpu -k "conv or outp or net or bprop or fc" > "$O/wgpf_tests.log" 2>&1
+echo "rc=$?" >> "$O/wgpf_tests.log"; tail -2 "$O/wgpf_tests.log"
+CONVNET_WG_PREFETCH=1 timeout 60 python tools/layer_bench.py > "$O/layer_wgpf.log" 2>&1
+paste <(grep wg_kernel "$O/layer_default.log") <(grep wg_kernel "$O/layer_wgpf.log" | awk '{print $(NF-1), $NF}') | head -20
+
 echo "== 3. one-wave-per-SIMD micro-benchmark, three schedules"
 for v in 0 1 2; do timeout 20 tools/wave1_gemm $v; done 2>&1 | tee "$O/wave1_gemm.log"
 
 echo "== 4. bench line (default) and with the three-stage kernel"
 timeout 120 python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"; cut -c1-200 "$O/bench_default.json"
 CONVNET_GG_STAGES3=1 timeout 120 python bench.py --no-cpu-baseline > "$O/bench_stages3.json" 2> "$O/bench_stages3.err"; cut -c1-200 "$O/bench_stages3.json"
+CONVNET_WG_PREFETCH=1 timeout 120 python bench.py --no-cpu-baseline > "$O/bench_wgpf.json" 2> "$O/bench_wgpf.err"; cut -c1-200 "$O/bench_wgpf.json"
+CONVNET_GG_STAGES3=1 CONVNET_WG_PREFETCH=1 timeout 120 python bench.py --no-cpu-baseline > "$O/bench_both.json" 2> "$O/bench_both.err"; cut -c1-200 "$O/bench_both.json"
 
 echo "== 5. HBM-side traffic after the pooling XCD order (two PMC passes, never combined)"
 cd /tmp && export TMPDIR=/tmp
