@@ -188,13 +188,14 @@ def profile_enable(on=True):
 
 
 def profile_report():
-    """[{kernel, op, launches, ms, flops, bytes}] for launches since the last report."""
+    """[{kernel, op, launches, ms, flops, bytes, executed}] for launches since the last report (flops = algorithmic work,
+    executed = MFMA work issued, which is larger for dgrad gathers that run border taps on the zero page)."""
     buf = ctypes.create_string_buffer(1 << 16)
     n = lib.convnet_hip_profile_report(buf, len(buf))
     rows = []
     for line in buf.value.decode().splitlines() if n else []:
-        k, op, cnt, ms, fl, by = line.split("|")
-        rows.append({"kernel": k, "op": op, "launches": int(cnt), "ms": float(ms), "flops": float(fl), "bytes": float(by)})
+        k, op, cnt, ms, fl, by, ex = line.split("|")
+        rows.append({"kernel": k, "op": op, "launches": int(cnt), "ms": float(ms), "flops": float(fl), "bytes": float(by), "executed": float(ex)})
     return rows
 
 

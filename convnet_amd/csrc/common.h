@@ -24,7 +24,9 @@ void note_kernel(const char* name, double flops, int blocks, int split_k);
 // Optional per-launch timing with HIP events on the library stream (bench.py's roofline leg).
 // Off by default: when off, KernelTimer is two predictable branches.
 struct KernelTimer {
-  KernelTimer(const char* name, const char* op, double flops, double bytes);
+  // flops = ALGORITHMIC work of the call (what bench.py's roofline divides by the event time); executed = the MFMA work the
+  // launch actually issues when that differs (dgrad gathers run border taps on the zero page); 0 = same as flops
+  KernelTimer(const char* name, const char* op, double flops, double bytes, double executed = 0.0);
   ~KernelTimer();
   int slot;
 };

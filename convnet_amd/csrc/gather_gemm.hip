@@ -183,13 +183,8 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT]
 // O3 = the 3-blocks-per-CU build (launch bound 3 waves/SIMD + the k-row-major B stage that makes it fit): chosen by the
 // host only for launches with enough tiles to fill >= 2 rounds of 768 slots, where it gains 2-6 %; on ~512-tile launches
 // the blocks spread 3/1 over the CUs and it loses, so the 2-block build stays the default.
-// ST = LDS stages.  2: double buffer (the measured default).  3 (EXPERIMENT, selected only by CONVNET_GG_STAGES3=1, r-contiguous
-// vector build): the loads of chunk c+2 are issued at the start of chunk c, so each load has two MFMA phases to land and the
-// chunk-closing wait is vmcnt(loads of one chunk) instead of vmcnt(0); the first fragments of chunk c+1 are read right after
-// that barrier, ahead of the last k-step's MFMAs, instead of in front of the first MFMA of chunk c+1 (NOTES.md).
-template <int WR, int WC, int MT, int CW, bool A_KCONTIG, bool VEC, bool O3 = false, int ST = 2>
+template <int WR, int WC, int MT, int CW, bool A_KCONTIG, bool VEC, bool O3 = false>
 __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGParams pin, const GGClassTable ct) {
-  static_assert(ST == 2 || (ST == 3 && VEC && !A_KCONTIG && !O3), "the 3-stage ring is a variant of the r-contiguous vector build");
   constexpr int NT = WR * WC * 64;
   constexpr int NTC = CW / 32, CW4 = CW / 4;
   using fvec = __attribute__((ext_vector_type(NTC))) float;
@@ -200,8 +195,8 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
   constexpr int NA = ((A_KCONTIG ? ROWS * (BK / 4) : BK * (ROWS / 4)) + NT - 1) / NT;
   constexpr int NB = (WC * BK * CW4 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                  // [ST][A_STAGE]
-  float* Bs = smem + ST * A_STAGE;   // [ST][B_STAGE]
+  float* As = smem;                 // [2][A_STAGE]
+  float* Bs = smem + 2 * A_STAGE;   // [2][B_STAGE]
 
   // fields a stride class overrides live in scalars; everything else is read from the kernarg struct in place
   const GGParams& p = pin;
@@ -501,75 +496,6 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
   constexpr bool SPREAD = false && GLDS_A && GLDS_B;
   constexpr bool PRIO = true;
   constexpr int NP = NA + NB, PPS = (NP + BK / 2 - 1) / (BK / 2);
-  if constexpr (ST == 3) {
-    // loads every wave of the block issues per chunk (slots whose 256-lane group lies wholly inside the tile): the chunk-closing
-    // wait may leave that many (the youngest = chunk c+2) outstanding; a wave that issued more waits for a few of them too
-    constexpr int A_ALL = (BK * (ROWS / 4)) / NT < NA ? (BK * (ROWS / 4)) / NT : NA;
-    constexpr int B_ALL = (WC * BK * CW4) / NT < NB ? (WC * BK * CW4) / NT : NB;
-    constexpr int NWAIT = A_ALL + B_ALL;
-    static_assert(NWAIT >= 1 && NWAIT < 64, "vmcnt immediate");
-    constexpr int WAIT_NEXT = (NWAIT & 15) | ((NWAIT >> 4) << 14) | 0x0070;   // vmcnt(NWAIT) expcnt(7) lgkmcnt(0)
-    if (nchunks > 1) fetch(kbeg + BK, 1);
-    float a[2][MT];
-    fvec b4[2];
-    {
-      const float* ar = As + wr * MT * 32 + li;
-      const float* bs = Bs + (KM ? wc * CW : wc * BK * CW) + NTC * li;
-#pragma unroll
-      for (int t = 0; t < MT; ++t) a[0][t] = ar[lh * ROWS + t * 32];
-      b4[0] = *reinterpret_cast<const fvec*>(bs + lh * BROW);
-    }
-    int buf = 0;
-    for (int c = 0; c < nchunks; ++c) {
-      const int nbuf = buf == 2 ? 0 : buf + 1, fbuf = nbuf == 2 ? 0 : nbuf + 1;
-      const bool more = c + 1 < nchunks, fill = c + 2 < nchunks;
-      if (fill) fetch(kbeg + (c + 2) * BK, fbuf);
-      const float* ar = As + buf * A_STAGE + wr * MT * 32 + li;
-      const float* bs = Bs + buf * B_STAGE + (KM ? wc * CW : wc * BK * CW) + NTC * li;
-      const float* arn = As + nbuf * A_STAGE + wr * MT * 32 + li;
-      const float* bsn = Bs + nbuf * B_STAGE + (KM ? wc * CW : wc * BK * CW) + NTC * li;
-      if (PRIO) __builtin_amdgcn_s_setprio(2);
-      static_for<0, BK / 2>([&](auto KK) __attribute__((always_inline)) {
-        constexpr int kk = decltype(KK)::value;
-        constexpr int cur = kk & 1, nxt = cur ^ 1;
-        constexpr int HALF = (MT + 1) / 2;   // row tiles issued before the look-ahead reads
-        // first part of this k-step's MFMAs, THEN the look-ahead reads: the compiler covers a fragment with lgkmcnt(0) whatever
-        // else is in flight, so reads issued directly above a wait stall it; issued here they have the second part to land
-#pragma unroll
-        for (int t = 0; t < HALF; ++t)
-#pragma unroll
-          for (int u = 0; u < NTC; ++u)
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], b4[cur][u], acc[t][u], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (kk + 1 < BK / 2) {
-          const int krow = 2 * (kk + 1) + lh;
-#pragma unroll
-          for (int t = 0; t < MT; ++t) a[nxt][t] = ar[krow * ROWS + t * 32];
-          b4[nxt] = *reinterpret_cast<const fvec*>(bs + krow * BROW);
-        } else {
-          // hand-over: chunk c+1 has landed (everything older than this wave's chunk-c+2 loads), every wave has read its
-          // last fragments of this stage (lgkmcnt(0)) so the stage may be refilled next chunk; then the first fragments of
-          // chunk c+1, covered by the rest of this k-step's MFMAs and the next chunk's staging block
-          if (more) {
-            if (fill) __builtin_amdgcn_s_waitcnt(WAIT_NEXT); else __builtin_amdgcn_s_waitcnt(0x0070);
-            __builtin_amdgcn_s_barrier();
-#pragma unroll
-            for (int t = 0; t < MT; ++t) a[nxt][t] = arn[lh * ROWS + t * 32];
-            b4[nxt] = *reinterpret_cast<const fvec*>(bsn + lh * BROW);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = HALF; t < MT; ++t)
-#pragma unroll
-          for (int u = 0; u < NTC; ++u)
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], b4[cur][u], acc[t][u], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      if (PRIO) __builtin_amdgcn_s_setprio(0);
-      buf = nbuf;
-    }
-  } else {
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
     const bool more = c + 1 < nchunks;
@@ -638,7 +564,6 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
     }
     if (c + 1 < nchunks) stash(buf ^ 1);
     __syncthreads();
-  }
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------
@@ -742,10 +667,7 @@ constexpr int WG_PITCH = WG_NB + 4;  // conflict-free ds_read_b128 across rows
 // tile; same FLOP/clk).  The 16-wide tiles let a 160 x 96 problem (conv1: 147 taps x 96 filters) split evenly
 // over 2x2 waves (80 x 48 each), which no arrangement of 32-wide tiles can: the 5-wave 32x32 config ran at 70
 // TFLOP/s with 10 waves on 4 SIMDs.
-// PF (EXPERIMENT, selected only by CONVNET_WG_PREFETCH=1): explicit double-buffered fragment registers with the next group's
-// ds_reads issued between the two halves of the current group's MFMAs.  In the default build the compiler overlaps a little
-// by itself but waits lgkmcnt(0) directly under the reads it has just issued, once per 16 MFMAs (NOTES.md).
-template <int WM, int WN, int MT, int NTL, bool VEC, int TS, bool PF = false>
+template <int WM, int WN, int MT, int NTL, bool VEC, int TS>
 __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int KT = WM * MT * TS;   // k-columns (D rows) per block
@@ -937,46 +859,6 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
     if (c + 1 < cend) fetch(c + 1, buf ^ 1);
     const float* ar = As + buf * A_STAGE + (wm * MT * TS + li) * PITCH;
     const float* br = Bs + buf * B_STAGE + (wn * NTL * TS + li) * PITCH;
-    if constexpr (PF) {
-      constexpr int Q = WG_NB / (4 * LH);
-      f32x4 a4[2][MT], b4[2][NTL];
-      {
-        const int piece = 4 * (lh ^ swz);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) a4[0][t] = ld4(ar + t * TS * PITCH + piece);
-#pragma unroll
-        for (int u = 0; u < NTL; ++u) b4[0][u] = ld4(br + u * TS * PITCH + piece);
-      }
-      static_for<0, Q>([&](auto QQ) __attribute__((always_inline)) {
-        constexpr int q = decltype(QQ)::value;
-        constexpr int cur = q & 1, nxt = cur ^ 1;
-        auto mfmas = [&](int e) __attribute__((always_inline)) {
-#pragma unroll
-          for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int u = 0; u < NTL; ++u) {
-              if constexpr (TS == 32)
-                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[cur][t][e], b4[cur][u][e], acc[t][u], 0, 0, 0);
-              else
-                acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[cur][t][e], b4[cur][u][e], acc[t][u], 0, 0, 0);
-            }
-        };
-        mfmas(0);
-        mfmas(1);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (q + 1 < Q) {
-          const int piece = 4 * ((LH * (q + 1) + lh) ^ swz);
-#pragma unroll
-          for (int t = 0; t < MT; ++t) a4[nxt][t] = ld4(ar + t * TS * PITCH + piece);
-#pragma unroll
-          for (int u = 0; u < NTL; ++u) b4[nxt][u] = ld4(br + u * TS * PITCH + piece);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(2);
-        mfmas(3);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    } else
 #pragma unroll
     for (int q = 0; q < WG_NB / (4 * LH); ++q) {   // one b128 per lane = 4*LH images of the stage
       const int piece = 4 * ((LH * q + lh) ^ swz);
@@ -1062,6 +944,7 @@ constexpr int kTargetBlocks = 512;  // ~2 resident blocks per CU
 // tag + algorithmic flops of the call being dispatched (consumed by KernelTimer in the launchers)
 const char* t_op = "";
 double t_flops = 0.0;
+double t_exec = 0.0;   // MFMA work the launch issues when it differs from the algorithmic t_flops (0 = same)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -1098,20 +981,9 @@ void gg_launch_classes(GGParams& p, GGClassTable& ct, bool vec) {
     ct.c[i].tile_end = end;
   }
   static const std::string kname = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ",rc>";
-  KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0);
+  KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, t_exec);
   dim3 grid(end), block(WR * WC * 64);
-  static const bool stages3 = [] { const char* e = getenv("CONVNET_GG_STAGES3"); return e && *e && *e != '0'; }();   // EXPERIMENT, see gg_kernel
-  bool done3 = false;
-  if constexpr ((WR == 2 && WC == 2 && MT == 2 && CW == 128) || (WR == 1 && WC == 4 && MT == 3 && CW == 64)) {
-    if (stages3 && vec) {
-      const size_t lds3 = lds / 2 * 3;
-      allow_big_lds(gg_kernel<WR, WC, MT, CW, false, true, false, 3>, lds3);
-      hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, false, true, false, 3>), grid, block, lds3, stream(), p, ct);
-      done3 = true;
-    }
-  }
-  if (done3) {
-  } else if (vec) {
+  if (vec) {
     allow_big_lds(gg_kernel<WR, WC, MT, CW, false, true>, lds);
     hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, false, true>), grid, block, lds, stream(), p, ct);
   } else {
@@ -1195,25 +1067,14 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   dim3 block(WR * WC * 64);
   static const std::string kname = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + "," + (AK ? "kc" : "rc") + ">";
   {
-    KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0);
+    KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, t_exec);
     if constexpr (!AK && WR == 2 && WC == 2 && MT == 2 && CW == 128) {
       if (o3) {
         allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, true, true>, lds);
         hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, true, true>), grid, block, lds, stream(), p, kNoClasses);
       }
     }
-    // EXPERIMENT, off unless CONVNET_GG_STAGES3=1: three LDS stages for the two r-contiguous vector builds AlexNet uses
-    static const bool stages3 = [] { const char* e = getenv("CONVNET_GG_STAGES3"); return e && *e && *e != '0'; }();
-    bool done3 = false;
-    if constexpr (!AK && ((WR == 2 && WC == 2 && MT == 2 && CW == 128) || (WR == 1 && WC == 4 && MT == 3 && CW == 64))) {
-      if (stages3 && vec && !o3) {
-        const size_t lds3 = sizeof(float) * 3 * (A_STAGE + B_STAGE);
-        allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, true, false, 3>, lds3);
-        hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, true, false, 3>), grid, block, lds3, stream(), p, kNoClasses);
-        done3 = true;
-      }
-    }
-    if (o3 || done3) {
+    if (o3) {
     } else if (vec) {
       allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, true>, lds);
       hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, true>), grid, block, lds, stream(), p, kNoClasses);
@@ -1297,16 +1158,10 @@ void wg_launch_cfg(WGParams& p, bool vec) {
   dim3 grid(((tiles * splits + 7) / 8) * 8), block(WM * WN * 64);
   static const std::string kname = "wg_kernel<" + std::to_string(WM) + "," + std::to_string(WN) + "," + std::to_string(MT) + "," + std::to_string(NTL) + (TS == 16 ? ",x16>" : ">");
   {
-    KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0);
+    KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, t_exec);
     if (vec) {
-      static const bool prefetch = [] { const char* e = getenv("CONVNET_WG_PREFETCH"); return e && *e && *e != '0'; }();   // EXPERIMENT, see wg_kernel
-      if (prefetch) {
-        allow_big_lds(wg_kernel<WM, WN, MT, NTL, true, TS, true>, lds);
-        hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, true, TS, true>), grid, block, lds, stream(), p);
-      } else {
-        allow_big_lds(wg_kernel<WM, WN, MT, NTL, true, TS>, lds);
-        hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, true, TS>), grid, block, lds, stream(), p);
-      }
+      allow_big_lds(wg_kernel<WM, WN, MT, NTL, true, TS>, lds);
+      hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, true, TS>), grid, block, lds, stream(), p);
     } else {
       allow_big_lds(wg_kernel<WM, WN, MT, NTL, false, TS>, lds);
       hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, false, TS>), grid, block, lds, stream(), p);
@@ -1392,6 +1247,7 @@ void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* tar
   const bool vec = g.N % 4 == 0 && g.F % 4 == 0 && aligned16(p.A) && aligned16(p.src) && aligned16(p.dst);
   t_op = "conv_fprop";
   t_flops = 2.0 * g.N * p.G * (double)g.F * p.K;
+  t_exec = 0.0;
   gg_run<false>(p, vec, (size_t)g.N * p.DP * g.F);
   note_kernel("gg_kernel(fprop)", 2.0 * g.N * p.G * (double)g.F * p.K, p.row_tiles * p.col_tiles, p.splits);
 }
@@ -1440,6 +1296,21 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
   GGClassTable ct{};
   const bool multi = g.sy * g.sx > 1 && g.sy * g.sx <= kMaxClasses;   // all classes in one launch (no wave-quantisation per class)
   t_op = "conv_dgrad";
+  // Work accounting.  ALGORITHMIC = the transposed convolution's MACs, 2*N*My*Mx*F*C*Ky*Kx (every output pixel meets every tap
+  // once — the same count as fprop).  EXECUTED = what the gather issues: every INPUT pixel of a class runs the class's whole tap
+  // set, border pixels on the zero page (conv5, pad 0: 169*9 vs 121*9 taps = 1.40x; conv2: 1.13x).  bench.py's roofline uses the
+  // algorithmic figure; the executed one travels beside it.
+  const double alg_flops = 2.0 * g.N * (double)g.My * g.Mx * (double)g.F * g.C * g.Ky * g.Kx;
+  double exec_total = 0;
+  for (int cy = 0; cy < g.sy; ++cy)
+    for (int cx = 0; cx < g.sx; ++cx) {
+      const int TYc = cy < g.Ky ? divup(g.Ky - cy, g.sy) : 0, TXc = cx < g.Kx ? divup(g.Kx - cx, g.sx) : 0;
+      const int ny = -g.py - cy, nx = -g.px - cx;
+      const int jy0 = ny > 0 ? (ny + g.sy - 1) / g.sy : 0, jx0 = nx > 0 ? (nx + g.sx - 1) / g.sx : 0;
+      const int iy0 = cy + g.py + g.sy * jy0, ix0 = cx + g.px + g.sx * jx0;
+      if (iy0 >= g.H || ix0 >= g.W) continue;
+      exec_total += 2.0 * g.N * (double)(((g.H - 1 - iy0) / g.sy + 1) * ((g.W - 1 - ix0) / g.sx + 1)) * g.C * (double)(g.F * TYc * TXc);
+    }
   for (int cy = 0; cy < g.sy; ++cy) {
     for (int cx = 0; cx < g.sx; ++cx) {
       const int TYc = cy < g.Ky ? divup(g.Ky - cy, g.sy) : 0;
@@ -1476,7 +1347,8 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
       GGParams p = base;
       p.A = k.A; p.K = k.K; p.GX = k.GX; p.G = k.G; p.TX = k.TX; p.TYX = k.TYX;
       p.y0 = k.y0; p.x0 = k.x0; p.dy0 = k.dy0; p.dx0 = k.dx0;
-      t_flops = cflops;
+      t_flops = exec_total > 0 ? alg_flops * (cflops / exec_total) : 0.0;
+      t_exec = cflops;
       // a stride-1 convolution has a single class that owns every input pixel: split-K is legal there
       const bool whole = g.sy == 1 && g.sx == 1 && GY == g.H && GX == g.W;
       gg_run<false>(p, vec, whole ? (size_t)g.N * g.H * g.W * g.C : 0);
@@ -1484,11 +1356,12 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
     }
   }
   if (multi && ct.n > 0) {
-    t_flops = flops;
+    t_flops = alg_flops;
+    t_exec = flops;
     gg_run_classes(base, ct, vec);
     blocks = ct.c[ct.n - 1].tile_end;
   }
-  note_kernel("gg_kernel(dgrad)", flops, blocks, 1);
+  note_kernel("gg_kernel(dgrad)", alg_flops, blocks, 1);
 }
 
 void convDownGemm(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* ds, Shape4D* fs, Shape4D* ts, ConvDesc d,
@@ -1523,6 +1396,7 @@ static void conv_outp_impl(cudamat* images, cudamat* derivs, cudamat* targets, c
   const bool vec = g.N % 4 == 0 && aligned16(p.src) && aligned16(p.dout);
   t_op = "conv_wgrad";
   t_flops = 2.0 * g.N * p.M * (double)g.F * p.K;
+  t_exec = 0.0;
   wg_launch(p, vec);
   note_kernel("wg_kernel(wgrad)", 2.0 * g.N * p.M * (double)g.F * p.K, p.k_tiles * p.f_tiles, p.splits);
   if (bias_grad && !p.bias_dst) {
@@ -1582,6 +1456,7 @@ static int dot_impl(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target
     const bool base_vec = m % 4 == 0 && aligned16(p.src) && aligned16(p.dst) && aligned16(p.A) && aligned16(p.mask);
     t_op = t2 ? "fc_fprop" : "fc_dgrad";
     t_flops = 2.0 * m * (double)n * K;
+    t_exec = 0.0;
     if (t2) {   // NT: A[r=f + F*k=d]
       gg_run<false>(p, base_vec && n % 4 == 0, (size_t)m * n);
     } else {    // NN: A[k=f + F*r=d]
@@ -1602,6 +1477,7 @@ static int dot_impl(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target
     const bool vec = K % 4 == 0 && aligned16(p.src) && aligned16(p.dout);
     t_op = "fc_wgrad";
     t_flops = 2.0 * m * (double)n * K;
+    t_exec = 0.0;
     wg_launch(p, vec);
     note_kernel("wg_kernel(fc TN)", 2.0 * m * (double)n * K, p.k_tiles * p.f_tiles, p.splits);
     return launch_status();

@@ -69,7 +69,7 @@ void note_kernel(const char* name, double flops, int blocks, int split_k) {
 namespace {
 struct ProfRec {
   std::string name, op;
-  double flops, bytes;
+  double flops, bytes, executed;
   hipEvent_t start, stop;
 };
 bool g_prof_on = false;
@@ -87,9 +87,9 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-KernelTimer::KernelTimer(const char* name, const char* op, double flops, double bytes) : slot(-1) {
+KernelTimer::KernelTimer(const char* name, const char* op, double flops, double bytes, double executed) : slot(-1) {
   if (!g_prof_on) return;
-  ProfRec r{name, op, flops, bytes, get_event(), get_event()};
+  ProfRec r{name, op, flops, bytes, executed > 0.0 ? executed : flops, get_event(), get_event()};
   CHIP_CHECK(hipEventRecord(r.start, g_stream));
   g_prof.push_back(r);
   slot = (int)g_prof.size() - 1;
@@ -176,18 +176,18 @@ void convnet_hip_last_kernel_info(ConvnetHipKernelInfo* out) { *out = g_info; }
 void convnet_hip_profile_enable(int on) { g_prof_on = on != 0; }
 
 // Synchronises the stream, aggregates the recorded launches by (kernel, op) into `buf` as text lines
-// "kernel|op|launches|total_ms|total_flops|total_bytes" and clears the records.  Returns the
+// "kernel|op|launches|total_ms|total_flops|total_bytes|total_executed_flops" and clears the records.  Returns the
 // number of bytes written (0 if nothing was recorded or the buffer is too small).
 size_t convnet_hip_profile_report(char* buf, size_t cap) {
   if (g_prof.empty()) return 0;
   hipStreamSynchronize(g_stream);
-  struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
+  struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0, executed = 0; };
   std::map<std::string, Agg> agg;
   for (auto& r : g_prof) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, r.start, r.stop);
     Agg& a = agg[r.name + "|" + r.op];
-    a.n++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+    a.n++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes; a.executed += r.executed;
     g_event_pool.push_back(r.start);
     g_event_pool.push_back(r.stop);
   }
@@ -195,7 +195,8 @@ size_t convnet_hip_profile_report(char* buf, size_t cap) {
   std::string out;
   char line[512];
   for (auto& kv : agg) {
-    snprintf(line, sizeof line, "%s|%ld|%.6f|%.6e|%.6e\n", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes);
+    snprintf(line, sizeof line, "%s|%ld|%.6f|%.6e|%.6e|%.6e\n", kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes,
+             kv.second.executed);
     out += line;
   }
   if (out.size() + 1 > cap) return 0;

@@ -10,34 +10,3 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _gpu_warm_up(request):
-    """Before the first GPU test of a session: load the library's code objects and run a handful of its kernels once, results
-    discarded.  (One unexplained failure of the very first GPU test of the very first process on a freshly booted box was seen in
-    round 1 and never again in 60+ repetitions; a first-launch effect is the only candidate, NOTES.md.)"""
-    if not any(item.get_closest_marker("gpu") for item in request.session.items):
-        return
-    try:
-        import torch
-        if not torch.cuda.is_available():
-            return
-        import numpy as np
-        from convnet_amd.matrix import Matrix
-        from hip_adapter import HipImpl
-        from oracle import Geom
-        Matrix.SetupCUDADevice(0)
-        hip = HipImpl()
-        rng = np.random.default_rng(0)
-        # the exact shapes of __graft_entry__.smoke(), which has run on the GPU box many times
-        g = Geom(N=32, C=16, H=13, W=13, F=48, Ky=3, Kx=3, sy=2, sx=2, pady=1, padx=1)
-        p = Geom(N=32, C=16, H=13, W=13, F=16, Ky=3, Kx=3, sy=2, sx=2, pady=1, padx=1)
-        x, w = rng.standard_normal(g.in_shape()).astype(np.float32), rng.standard_normal(g.filt_shape()).astype(np.float32)
-        for _ in range(2):
-            hip.conv_up(g, x, w)
-            hip.max_pool(p, np.maximum(x, 0))
-            hip.rnorm(x, 4, 0.005, 0.75)
-        torch.cuda.synchronize()
-    except Exception as e:   # noqa: BLE001 — a warm-up must never be the reason a session fails; the tests will tell
-        print(f"gpu warm-up skipped: {e!r}")

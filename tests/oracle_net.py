@@ -15,8 +15,11 @@ def _geom(e, src, N, pool=False):
                 -d.padding_y, -d.padding_x)
 
 
-def forward_backward(net, x, labels, impl=None, force=None):
-    """``force`` = (states, derivs) dicts of flat arrays taken from the device run: the BACKWARD ops are then each fed
+def forward_backward(net, x, labels, impl=None, force=None, dropout_states=None):
+    """``dropout_states`` = {layer name: the device's post-dropout state}: the run is a TRAINING pass and a layer with
+    dropprob > 0 applies the device's own Bernoulli mask (recovered as state != 0; the CPU cannot replay the GPU's RNG) with
+    the train-time scale-up 1/(1-p) (src/layer.cc:367-397), and on the way back dropout' then ReLU' (layer.cc:399-413,556-558).
+    ``force`` = (states, derivs) dicts of flat arrays taken from the device run: the BACKWARD ops are then each fed
     the device's own inputs (teacher forcing), so one ReLU unit or pool window that gates differently within fp32
     rounding cannot colour everything upstream of it — every op is still checked on realistic whole-net data."""
     from convnet_amd.edge import AvgPoolEdge, ConvEdge, ConvOneToOneEdge, FCEdge, MaxPoolEdge, ResponseNormEdge
@@ -53,6 +56,9 @@ def forward_backward(net, x, labels, impl=None, force=None):
             raise NotImplementedError(type(e))
         if l.is_relu:
             y = O.lower_bound(y, 0.0)
+        if dropout_states is not None and l.dropprob_ > 0:
+            assert l.is_relu and not l.store_dropout_noise_
+            y = y * ((dropout_states[l.GetName()] != 0).astype(np.float32) * np.float32(1.0 / (1 - l.dropprob_)))
         if l.IsOutput():
             y = O.softmax_row_major(y.reshape(l.GetNumChannels(), N)).reshape(-1)
         acts[l.GetName()] = y
@@ -94,6 +100,8 @@ def forward_backward(net, x, labels, impl=None, force=None):
             dx = O.rnorm_undo(dy.reshape(C, -1, 1, N), a.reshape(C, -1, 1, N), e.num_filters_response_norm_, e.add_scale_, e.pow_scale_,
                               e.blocked_).reshape(-1)
         if dx is not None and not l.IsInput():
+            if dropout_states is not None and l.dropprob_ > 0:
+                dx = dx * np.float32(1.0 / (1 - l.dropprob_))
             if l.is_relu:
                 dx = O.relu_deriv(dx, a)
             derivs[l.GetName()] = dx

@@ -202,3 +202,28 @@ def h5_listing(path):
             attrs.append(buf.value.decode())
         L.H5Gclose(root)
     return sorted(names), sorted(attrs)
+
+
+def golden_params(total, seed, slices):
+    """Deterministic integer-hash parameters for the full-size golden runs (no RNG library involved, identical on every
+    machine): unit-variance uniform hash values scaled per edge slice to sqrt(2 / fan_in) so the 8-layer net neither
+    saturates nor dies.  ``slices`` = [(offset, floats, dest_channels)] of the edges with parameters; fan_in = floats /
+    dest_channels - 1 (weights F x K plus F biases share the slice, src/convnet.cc:271-296)."""
+    p = np.zeros(total, np.float32)
+    u = hash_batch(seed + 17, 3, total, True)
+    for off, n, F in slices:
+        fan_in = n // F - 1
+        p[off:off + n] = u[off:off + n] * np.float32(np.sqrt(2.0 / fan_in))
+    return p
+
+
+def slices_from_describe(layers, edges):
+    """[(offset, floats, dest_channels)] with the reference's 128-float slice alignment, from RefHost.describe()."""
+    chans = {name: c for name, _, _, c, _, _ in layers}
+    out, off = [], 0
+    for _, dst, n in edges:
+        if n == 0:
+            continue
+        out.append((off, n, chans[dst]))
+        off += (n + 127) // 128 * 128
+    return out, off

@@ -194,11 +194,16 @@ def test_softmax_family_and_fused(hip):
     z = (3 * rnd(rng, (K, N)))
     labels = rng.integers(0, K, N).astype(np.float32)
     p_ref = oracle.port.softmax_row_major(z.copy())
-    # probabilities span 1e-9..0.5: compare element-wise relative (expf ulp + summation order)
-    assert np.allclose(hip.softmax_row_major(z.copy()), p_ref, rtol=1e-5, atol=1e-12)
-    assert np.array_equal(hip.softmax_correct_row_major(p_ref, labels), oracle.port.softmax_correct_row_major(p_ref, labels))
-    assert rel_err(hip.softmax_ce_row_major(p_ref, labels), oracle.port.softmax_ce_row_major(p_ref, labels)) < 1e-5
-    assert np.array_equal(hip.softmax_grad_row_major(p_ref, labels), oracle.port.softmax_grad_row_major(p_ref, labels))
+    # probabilities span 1e-9..0.5: compare element-wise relative (expf ulp + summation order).  Every assertion names what it
+    # saw: this test once failed as the first GPU test of a fresh box (NOTES.md) and the message was lost.
+    p_hip = hip.softmax_row_major(z.copy())
+    assert np.allclose(p_hip, p_ref, rtol=1e-5, atol=1e-12), ("softmax", float(np.abs(p_hip / p_ref - 1).max()), int(np.isnan(p_hip).sum()))
+    c_hip, c_ref = hip.softmax_correct_row_major(p_ref, labels), oracle.port.softmax_correct_row_major(p_ref, labels)
+    assert np.array_equal(c_hip, c_ref), ("correct", np.flatnonzero(c_hip != c_ref)[:8])
+    e = rel_err(hip.softmax_ce_row_major(p_ref, labels), oracle.port.softmax_ce_row_major(p_ref, labels))
+    assert e < 1e-5, ("cross entropy", e)
+    g_hip, g_ref = hip.softmax_grad_row_major(p_ref, labels), oracle.port.softmax_grad_row_major(p_ref, labels)
+    assert np.array_equal(g_hip, g_ref), ("CE derivative", float(np.abs(g_hip - g_ref).max()))
     # fused: softmax + CE-deriv + correct count
     Z, L = _mat(z, N, K), _mat(labels, N, 1)
     P, D, C = _mat(np.zeros_like(z), N, K), _mat(np.zeros_like(z), N, K), _mat(np.zeros(1, np.float32), 1, 1)
