@@ -8,7 +8,8 @@ exchange]) of the AlexNet-class model (BASELINE.json metric) on N MI355X GPUs of
 
 One process per GPU.  Each rank trains a full replica on its own synthetic batch of --batch images
 (weak scaling, exactly the reference's train_convnet_data_parallel semantics: every MPI rank reads
-its own batch of `batch_size` and the gradients are averaged, src/convnet.cc:407-450).  Rank 0 prints
+its own batch of `batch_size` and the gradients are averaged, src/convnet.cc:407-450); with
+--global-batch G the ranks share G images per step (strong scaling, G/N each).  Rank 0 prints
 ONE JSON line.  `value` = images processed by all ranks / max-over-ranks wall time of K steps,
 bracketed by barrier + torch.cuda.synchronize().
 
@@ -20,6 +21,8 @@ Extra objects on the line:
   cpu_baseline  the reference's own CPU path (oracle/_ref, eigenmat+CPUMatrix compiled unmodified)
                 — or the C port if that build is absent — running the same model's training step
                 on a bounded sample (N=6 images, 1 step, ~13 s), rank 0, N=1 only.
+  ref_host      the reference's unmodified C++ host loop on this library (same model, batch, step count),
+                timed after the product run in a child process; rank 0, N=1 only (--no-ref-host skips it).
 """
 import argparse
 import json
@@ -54,7 +57,8 @@ def pmc_traffic(kernel, args):
             fam = name.replace(" ", "")
             if fam.startswith(want.split(",rc")[0].split(",kc")[0]) and (",true,true," in fam) == want.endswith(",kc>"):
                 return {"traffic": rec["traffic_bytes"], "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, fabric side)",
-                        "traffic_source": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))}
+                        "traffic_source": "NOT measured in this run (PMC needs rocprofv3 around the process): read from the committed "
+                                          "passes of this same command, " + os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))}
     return {"traffic": None}
 
 
@@ -128,6 +132,29 @@ def cpu_baseline(sample_n=6):   # ~13 s of CPU work on the 256-core GPU box (N=2
                       f"(eigenmat.cc:2284-2298), only its pooling/softmax loops use OpenMP"}
 
 
+def ref_host_leg(args):
+    """The north-star driver on the same clock: the reference's UNMODIFIED C++ host (src/convnet.cc ConvNet::TrainOneBatch over its own
+    Layer / Edge / SGDOptimizer / Matrix, compiled from /root/reference by oracle/Makefile into oracle/_ref/libref_host_hip.so) linked
+    to this library, stepping the same model and batch.  Reported beside the product number, never part of it: it runs after the
+    timed region, in a child process (its own HIP context), through tools/ref_host_bench.py."""
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "_ref", "libref_host_hip.so")
+    if not os.path.exists(so):
+        return {"value": None, "note": "oracle/_ref/libref_host_hip.so not built on this box (needs /root/reference at build time)"}
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "ref_host_bench.py"), "--model", args.model, "--batch", str(args.batch),
+           "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        j = json.loads(line)
+        return {"value": round(j["value"], 2), "unit": "images/sec", "ms_per_step": round(j["ms_per_step"], 3), "steps": j["steps"],
+                "warmup": j["warmup"], "host": "reference src/*.cc unmodified -> reference Matrix (src/matrix.cc) -> this library; "
+                                               "unfused cudamat call sequence, one metric read-back per step",
+                "last_loss": j.get("last_loss")}
+    except Exception as e:   # noqa: BLE001 — a reported extra, never a reason to lose the bench line
+        return {"value": None, "note": f"failed: {e!r}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,6 +172,12 @@ def main():
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=8.0)
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange path even with 1 rank (self-test)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling (SURVEY 8(d) config 4): this many images per step in total, split evenly over the ranks "
+                         "(--batch is ignored); default 0 = weak scaling, --batch images on every rank")
+    ap.add_argument("--no-ref-host", action="store_true",
+                    help="skip the `ref_host` leg (the reference's own unmodified C++ ConvNet::TrainOneBatch loop linked to this library, "
+                         "tools/ref_host_bench.py, timed in a child process after the product run; rank 0, 1 GPU only)")
     args = ap.parse_args()
 
     # RCCL prints a version banner on the C-level stdout at communicator creation; keep the real stdout
@@ -165,6 +198,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    strong = args.global_batch > 0
+    if strong:
+        assert args.global_batch % world == 0, f"--global-batch {args.global_batch} does not divide over {world} ranks"
+        args.batch = args.global_batch // world
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
     Matrix.SetupCUDADevice(local_rank)
     exchange = None
@@ -233,19 +270,23 @@ def main():
         ms_per_step = 1e3 * dt / args.steps
         fam = {}
         for r in prof:
-            f = fam.setdefault(r["kernel"], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
-            for k in ("launches", "ms", "flops", "bytes"):
+            f = fam.setdefault(r["kernel"], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "executed": 0.0})
+            for k in ("launches", "ms", "flops", "bytes", "executed"):
                 f[k] += r[k]
         mfma = {k: v for k, v in fam.items() if v["flops"] > 0}
         roofline = None
         if mfma:
             dom_name, dom = max(mfma.items(), key=lambda kv: kv[1]["ms"])
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            executed = dom["executed"] / (dom["ms"] * 1e-3) / 1e12
             all_flops = sum(v["flops"] for v in mfma.values())
             all_ms = sum(v["ms"] for v in mfma.values())
             roofline = {
                 "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
+                # `achieved` counts ALGORITHMIC flops (2*N*My*Mx*F*C*Ky*Kx for every conv direction, 2*M*N*K for FC); `executed`
+                # also counts the MFMA work a dgrad gather spends on border taps that read the zero page
+                "executed": round(executed, 2), "executed_frac": round(executed / PEAK_FP32_MATRIX_TFLOPS, 4),
                 **pmc_traffic(dom_name, args),
                 "flops_per_launch": dom["flops"] / dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                 "launches": dom["launches"], "sampled_steps": timed_steps,
@@ -254,7 +295,8 @@ def main():
                                      "ms_per_step": round(all_ms / timed_steps, 3)},
                 "model_frac": round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
                 "families": {k: {"launches_per_step": v["launches"] / timed_steps, "ms_per_step": round(v["ms"] / timed_steps, 4),
-                                 **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] > 0 else
+                                 **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                     "executed_tflops": round(v["executed"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] > 0 else
                                     {"gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)})}
                              for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
                 "ops": {f'{r["kernel"]}|{r["op"]}': round(r["ms"] / timed_steps, 4) for r in sorted(prof, key=lambda r: -r["ms"])},
@@ -262,13 +304,14 @@ def main():
         out = {
             "metric": "images/sec (fprop+bprop+wgrad) AlexNet 224x224 bs=256" if args.model == "alexnet" else f"images/sec {args.model}",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.model} (convnet_amd.models.{args.model}" + (": the reference's AlexNet-class ILSVRC pbtxt) " if args.model == "alexnet" else ") ") +
                                    f"training step, 224x224x3 synthetic " + ("uint8-valued 256x256 chunk, random crop+flip staged on the GPU each step, " if args.staged_input else "N(0,1) images, ") + f"{args.batch} images per GPU, "
                                    f"SGD+momentum+L2, dropout on, {'fused' if not args.unfused else 'unfused'} ABI calls",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}" + ("" if world == 1 else (" rccl-allreduce " + ("overlapped" if not args.no_overlap else "serial"))),
+                       "parallelism": f"dp{world}" + ("" if world == 1 else (" rccl-allreduce " + ("overlapped" if not args.no_overlap else "serial")))
+                                      + (f" strong (global batch {args.global_batch} = {args.batch}/GPU)" if strong else f" weak ({args.batch}/GPU)"),
                        "params": net.NumParameters(), "train_gflop_per_image": round(2e-9 * train_macs, 4)},
             "roofline": roofline,
         }
@@ -277,6 +320,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline is a report, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+        if world == 1 and not args.no_ref_host and args.model in ("alexnet", "alexnet_nin") and not args.staged_input:
+            out["ref_host"] = ref_host_leg(args)
         result_line = json.dumps(out)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -7,8 +7,12 @@ biases perturb by +-epsilon, re-run Fprop(false), and compare
 (L(w+e) - L(w-e)) / (2 e batch) with the analytic value; an edge passes if the mean of
 |a-n| / |(a+n)/2| over non-zero entries is < 0.01 for ANY epsilon (src/grad_check.cc:37-75).
 The HDF5 dump of the arrays is replaced by the returned dict (HDF5 output is a §8f "next" row)."""
+import numpy as np
+
 from .convnet import ConvNet
 from .edge import EdgeWithWeight
+
+_f = np.float32   # the reference does all of this arithmetic in `float`
 
 
 class GradChecker(ConvNet):
@@ -27,38 +31,47 @@ class GradChecker(ConvNet):
         out = []
         for i in range(num_params):
             val = w.ReadValue(i)
-            w.WriteValue(i, val + epsilon)
+            w.WriteValue(i, float(_f(val) + _f(epsilon)))
             e1 = self.GetLoss()
-            w.WriteValue(i, val - epsilon)
+            w.WriteValue(i, float(_f(val) - _f(epsilon)))
             e2 = self.GetLoss()
-            out.append((e1[0] - e2[0]) / (self.batch_size_ * 2 * epsilon))
+            out.append(float((_f(e1[0]) - _f(e2[0])) / (_f(self.batch_size_ * 2) * _f(epsilon))))
             w.WriteValue(i, val)
         return out
 
     def GradCheck(self, w, eps_values, num_params, analytical_g):
         # src/grad_check.cc:37-75 (including its quirk: diff_sum carries over between epsilons)
-        diff_sum, non_zero, test_pass, numerical = 0.0, 0, False, {}
+        diff_sum, non_zero, test_pass, numerical = _f(0.0), 0, False, {}
         for eps in eps_values:
             if test_pass:
                 break
             this_num = self.ComputeNumericGrad(w, eps, num_params)
             for k in range(num_params):
-                diff = analytical_g[k] - this_num[k]
-                scale = (analytical_g[k] + this_num[k]) / 2
+                diff = _f(analytical_g[k]) - _f(this_num[k])
+                scale = (_f(analytical_g[k]) + _f(this_num[k])) / _f(2)
                 if not (scale == 0 and diff == 0):
-                    diff_sum += abs(diff / scale)
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        diff_sum = _f(diff_sum + abs(diff / scale))
                     non_zero += 1
-            diff_sum /= max(non_zero, 1)
+            # grad_check.cc:59: float division, 0/0 = NaN when every entry is exactly zero — and NaN < 0.01 is false, so an
+            # all-zero (dead unit) gradient is reported FAILED by the reference; kept
+            diff_sum = _f(diff_sum / _f(non_zero)) if non_zero else _f("nan")
             numerical[eps] = (this_num, diff_sum)
             if diff_sum < 0.01:
                 test_pass = True
         return test_pass, numerical
 
-    def Run(self):
-        """Returns {edge name: {"weights": (passed, analytical, numerical), "bias": (...)}}."""
+    def Run(self, fixed_batch=False):
+        """Returns {edge name: {"weights": (passed, analytical, numerical), "bias": (...)}}.
+        ``fixed_batch``: differentiate at the data handler's next batch instead of the reference's random fill, so that two
+        back-ends can be checked at the same point (tests; the reference's own flow is the default)."""
         for l in self.layers_:
             l.ResetAddOrOverwrite()
+        if fixed_batch:
+            self.GetBatch(self.train_dataset_)
         for l in self.data_layers_:
+            if fixed_batch:
+                break
             if l.IsInput():
                 l.GetState().FillWithRandn()
             else:

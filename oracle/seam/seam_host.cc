@@ -352,4 +352,66 @@ void seam_host_grad_check(const char* model_pbtxt, int batch_size, const char* o
   gc.Run(output_h5);
 }
 
+// run_grad_check on a FIXED point: GradChecker::Run (src/grad_check.cc:77-140) with its random fill of the inputs and labels
+// replaced by the data shim's batch 0 and the parameters supplied by the caller, so the reference's CPU build and its build on
+// this library differentiate the SAME function at the SAME point and their verdicts can be compared check by check.  Everything
+// that decides — ComputeNumericGrad, the pass rule (grad_check.cc:37-75, including its carry-over of diff_sum), the HDF5 datasets —
+// is the reference's own compiled GradChecker::GradCheck.  passed_out[2*i], [2*i+1] = weights / bias verdict of the i-th edge
+// with grad_check: true; returns the number of such edges.
+namespace {
+class SeamGradChecker : public GradChecker {
+ public:
+  explicit SeamGradChecker(const string& model_file) : GradChecker(model_file) {}
+  int RunFixed(const float* params, const string& output_file, int* passed_out, int cap) {
+    if (params) {
+      memcpy(parameters_.GetHostData(), params, sizeof(float) * (size_t)parameters_.GetRows() * parameters_.GetCols());
+      parameters_.CopyToDevice();
+    }
+    hid_t file = H5Fcreate(output_file.c_str(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+    for (Layer* l : layers_) l->ResetAddOrOverwrite();
+    GetBatch(*train_dataset_);
+    Fprop(false);
+    ComputeDeriv();
+    Bprop();
+    int n = 0;
+    for (Edge* ed : edges_) {
+      if (!ed->GradCheck()) continue;
+      EdgeWithWeight* e = dynamic_cast<EdgeWithWeight*>(ed);
+      if (e == NULL) continue;
+      const string& name = e->GetName();
+      vector<float> eps_values;
+      ed->GradCheckEpsilon(eps_values);
+      Matrix& gw = e->GetGradWeight();
+      Matrix& gb = e->GetGradBias();
+      gw.CopyToHost();
+      gb.CopyToHost();
+      int nw = ed->GradCheckNumParams(), nb = ed->GradCheckNumParams();
+      if (nw > gw.GetNumEls()) nw = gw.GetNumEls();
+      if (nb > gb.GetNumEls()) nb = gb.GetNumEls();
+      // the analytical gradients must outlive the perturbation loop (GetHostData of the live gradient matrix does, as in Run)
+      WriteHDF5CPU(file, gw.GetHostData(), nw, 1, name + "_weights_analytical");
+      WriteHDF5CPU(file, gb.GetHostData(), nb, 1, name + "_bias_analytical");
+      const bool pw = GradCheck(e->GetWeight(), eps_values, nw, gw.GetHostData(), name + "_weights_numerical", file);
+      const bool pb = GradCheck(e->GetBias(), eps_values, nb, gb.GetHostData(), name + "_bias_numerical", file);
+      if (2 * n + 1 < cap) {
+        passed_out[2 * n] = pw;
+        passed_out[2 * n + 1] = pb;
+      }
+      ++n;
+    }
+    H5Fclose(file);
+    return n;
+  }
+};
+}  // namespace
+
+int seam_host_grad_check_fixed(const char* model_pbtxt, const char* data_pbtxt, const float* params_in, const char* output_h5,
+                               int* passed_out, int cap) {
+  setup_device();
+  SeamGradChecker gc(model_pbtxt);
+  gc.SetupDataset(data_pbtxt);
+  gc.AllocateMemory(false);
+  return gc.RunFixed(params_in, output_h5, passed_out, cap);
+}
+
 }  // extern "C"

@@ -53,6 +53,8 @@ class RefHost:
         self.lib.seam_host_sgd.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         self.lib.seam_host_grad_check.restype = None
         self.lib.seam_host_grad_check.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
+        self.lib.seam_host_grad_check_fixed.restype = ctypes.c_int
+        self.lib.seam_host_grad_check_fixed.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int]
 
     def _call(self, model, data, steps, p_in, cap):
         out = np.zeros(cap, np.float32) if cap else None
@@ -130,6 +132,17 @@ class RefHost:
     def grad_check(self, model, batch, out_h5):
         """apps/run_grad_check.cc: GradChecker::Run writing <edge>_{weights,bias}_{analytical,numerical} to `out_h5`."""
         self.lib.seam_host_grad_check(str(model).encode(), batch, str(out_h5).encode())
+
+
+    def grad_check_fixed(self, model, data, params, out_h5):
+        """GradChecker on the data shim's batch 0 at the given parameters (seam_host.cc SeamGradChecker::RunFixed): the reference's
+        own compiled pass/fail verdicts, [(weights_passed, bias_passed)] per grad_check edge in edge order; arrays go to `out_h5`."""
+        p = np.ascontiguousarray(params, np.float32)
+        flags = np.full(256, -1, np.int32)
+        n = self.lib.seam_host_grad_check_fixed(str(model).encode(), str(data).encode(), p.ctypes.data, str(out_h5).encode(), flags.ctypes.data,
+                                                flags.size)
+        assert 0 < n <= flags.size // 2
+        return [(bool(flags[2 * i]), bool(flags[2 * i + 1])) for i in range(n)]
 
 
 def write_configs(tmp, model_text, batch, num_batches, seed, name="net"):
