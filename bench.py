@@ -172,6 +172,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=8.0)
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange path even with 1 rank (self-test)")
+    ap.add_argument("--transport", default="torch", choices=["torch", "abi"],
+                    help="gradient exchange through torch.distributed collectives (default) or through the library's own "
+                         "convnet_hip_comm_* entries (the path a C/C++ host drives)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="STRONG scaling (SURVEY 8(d) config 4): this many images per step in total, split evenly over the ranks "
                          "(--batch is ignored); default 0 = weak scaling, --batch images on every rank")
@@ -210,7 +213,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         from convnet_amd.data_parallel import GradientExchange
-        exchange = GradientExchange(bucket_bytes=int(args.bucket_mb * (1 << 20)), overlap=not args.no_overlap)
+        exchange = GradientExchange(bucket_bytes=int(args.bucket_mb * (1 << 20)), overlap=not args.no_overlap, transport=args.transport)
 
     text = getattr(models, args.model)()
     net = ConvNet(text, fused=not args.unfused, process_id=rank, num_processes=world, exchange=exchange,
@@ -310,7 +313,7 @@ def main():
                                    f"training step, 224x224x3 synthetic " + ("uint8-valued 256x256 chunk, random crop+flip staged on the GPU each step, " if args.staged_input else "N(0,1) images, ") + f"{args.batch} images per GPU, "
                                    f"SGD+momentum+L2, dropout on, {'fused' if not args.unfused else 'unfused'} ABI calls",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}" + ("" if world == 1 else (" rccl-allreduce " + ("overlapped" if not args.no_overlap else "serial")))
+                       "parallelism": f"dp{world}" + ("" if world == 1 else (" rccl-allreduce " + ("overlapped" if not args.no_overlap else "serial") + (" (C-ABI entries)" if args.transport == "abi" else "")))
                                       + (f" strong (global batch {args.global_batch} = {args.batch}/GPU)" if strong else f" weak ({args.batch}/GPU)"),
                        "params": net.NumParameters(), "train_gflop_per_image": round(2e-9 * train_macs, 4)},
             "roofline": roofline,

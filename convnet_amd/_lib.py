@@ -95,6 +95,16 @@ def _load():
     sig("convnet_hip_last_kernel_info", None, P(KernelInfo))
     sig("convnet_hip_profile_enable", None, I)
     sig("convnet_hip_profile_report", ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t)
+    # data-parallel exchange (csrc/comm.hip)
+    sig("convnet_hip_comm_unique_id", I, ctypes.c_char_p)
+    sig("convnet_hip_comm_init", I, I, I, ctypes.c_char_p)
+    sig("convnet_hip_comm_rank", I)
+    sig("convnet_hip_comm_size", I)
+    sig("convnet_hip_comm_broadcast", I, P(cudamat), I)
+    sig("convnet_hip_comm_allreduce_avg", I, P(cudamat), ctypes.c_size_t, ctypes.c_size_t, I)
+    sig("convnet_hip_comm_wait", I, I)
+    sig("convnet_hip_comm_sync", I)
+    sig("convnet_hip_comm_destroy", I)
     for n in ("allocate_device_memory", "free_device_memory", "copy_to_host", "copy_to_device"):
         sig(n, I, M)
     sig("copy_to_host_slice", I, M, ctypes.c_size_t, ctypes.c_size_t)

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libconvnet_hip.so")
-SOURCES = ["state.hip", "gather_gemm.hip", "pool_norm.hip", "elementwise.hip", "input_staging.hip"]
+SOURCES = ["state.hip", "gather_gemm.hip", "pool_norm.hip", "elementwise.hip", "input_staging.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
 
 
@@ -45,7 +45,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("hipcc failed")
     if force or procs or _stale(OUT, objs):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs]
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs, "-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             print(r.stdout, r.stderr, file=sys.stderr)

@@ -250,21 +250,28 @@ class ConvNet(TrainLoopMixin):
             self._pending_updates = [(e, now, False) for e, _, _ in self._pending_updates]
             self._flush_updates(final=False)
         edge.ComputeOuter(input.GetState(), output.GetDeriv())
-        if self.exchange_ is not None and edge in self.edge_slices_:
-            self.exchange_.GradReady(edge)      # wgrad of this edge is final: start its all-reduce
+        # The gradient slice belongs to the OWNER of the weights: an edge tied to another one (tied_to) accumulates into its
+        # owner's slice (edge_with_weight.cc:66-90), so the slice is final only when the last sharing edge has added its part —
+        # whichever of them comes last in backward order.
+        owner = edge.tied_edge_ if edge.IsTied() else edge
+        complete = isinstance(owner, EdgeWithWeight) and owner.GetNumGradsReceived() >= owner.num_shares_
+        if self.exchange_ is not None and owner in self.edge_slices_ and complete:
+            self.exchange_.GradReady(owner)     # the slice is final: start its all-reduce
         if not input.IsInput():
             overwrite = input.AddOrOverwriteDeriv(edge.GetSourceSliceName())
             if fuse_mask is not None:
                 edge.ComputeDown(output.GetDeriv(), input.GetState(), output.GetState(), input.GetDeriv(), overwrite, fuse_mask=fuse_mask)
             else:
                 edge.ComputeDown(output.GetDeriv(), input.GetState(), output.GetState(), input.GetDeriv(), overwrite)
-        if side and isinstance(edge, EdgeWithWeight):
+        if side and isinstance(owner, EdgeWithWeight) and complete:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())   # wgrad AND dgrad (which reads the weights) are enqueued
             # An FC edge's backward at batch <= a few hundred is itself HBM-bound (it streams the weight matrix
             # three times), so running its update beside it gains nothing: hold it until a conv edge's backward
             # (MFMA-bound) begins.  Conv updates are small and start at once.
-            self._pending_updates.append((edge, ev, isinstance(edge, FCEdge)))
+            # (Weights shared by tied edges are also READ by the sharers' ComputeDown: every sharer's dgrad precedes the
+            # completing ComputeOuter in program order except the completing edge's own, enqueued just above — so `ev` covers all.)
+            self._pending_updates.append((owner, ev, isinstance(owner, FCEdge)))
             self._flush_updates(final=False)
 
     def _flush_updates(self, final):
@@ -284,9 +291,11 @@ class ConvNet(TrainLoopMixin):
                     continue
                 bucket_ev = state
             self.side_stream_.wait_event(ev)
-            if bucket_ev is not None:
+            if bucket_ev is not None and not hasattr(bucket_ev, "wait_library_stream"):
                 self.side_stream_.wait_event(bucket_ev)
             with Matrix.OnStream(self.side_stream_):
+                if hasattr(bucket_ev, "wait_library_stream"):
+                    bucket_ev.wait_library_stream()      # exchange through the library's own entries: it holds the done-events
                 edge.UpdateWeights()
         self._pending_updates = keep
 
@@ -326,11 +335,22 @@ class ConvNet(TrainLoopMixin):
                 l.ComputeDeriv()
 
     def GetLoss(self):
-        """Per-output-layer performance metric (src/convnet.cc:456-461).  In fused mode the count
-        accumulates on device (no per-step sync) and GetLoss returns None."""
-        if self.fused:
+        """Per-output-layer performance metric (src/convnet.cc:456-461).  In fused mode a softmax output's correct count
+        accumulates on device (no per-step sync; ReadCorrectCount) and GetLoss returns None — unless some output layer did not
+        take the fused softmax path (e.g. a SQUARED_ERROR linear output) or there are several outputs: the on-device counter
+        is one number, so those nets report per layer through the reference's own call, like the unfused path."""
+        if self.fused and len(self.output_layers_) == 1 and isinstance(self.output_layers_[0], SoftmaxLayer):
             return None
         return [l.GetPerformanceMetric() for l in self.output_layers_]
+
+    def TimestampModel(self):
+        """ConvNet::TimestampModel (src/convnet.cc:830-838): stamp the run so checkpoints are <dir>/<name>_<timestamp>.h5."""
+        import time
+        ts = time.strftime("%Y%m%d%H%M%S")
+        if self.model_.timestamp is None:
+            self.model_.timestamp = []
+        self.model_.timestamp.append(ts)
+        return ts
 
     def ReadCorrectCount(self, reset=True):
         """Fused mode: number of correct predictions since the last read (one D2H sync)."""
@@ -408,7 +428,16 @@ class ConvNet(TrainLoopMixin):
         plus ``__lr_reduce_counter__`` and ``__current_iter__``; written to ``<name>temp`` and renamed (convnet.cc:666-684)."""
         import os
         from . import hdf5io
-        output_file = output_file or self.GetCheckpointFilename()
+        if output_file is None:
+            # ConvNet::Save() (src/convnet.cc:659-667): the checkpoint, then — with Polyak averaging on — the AVERAGED weights
+            # beside it as <file>polyak, and the current weights restored
+            fname = self.GetCheckpointFilename()
+            self.Save(fname)
+            if self.model_.polyak_after > 0:
+                self.LoadPolyakWeights()
+                self.Save(fname + "polyak")
+                self.LoadCurrentWeights()
+            return
         tmp = output_file + "temp"
         with hdf5io.File(tmp, "w") as f:
             for e in self.edges_:

@@ -935,6 +935,58 @@ __global__ void wg_reduce_kernel(float* __restrict__ dst, float* __restrict__ ds
 }
 
 // -------------------------------------------------------------------------------------------------
+// dot() outside the three fc_edge.cc shapes: target = beta*target + alpha*op(mat1)*op(mat2) for ANY transpose combination and
+// any alpha (the full contract of cudamat.cu:2130-2152, which hands all four cases to cublasSgemm).  Off the hot path — T,T and
+// alpha != 1 on the N,x side never occur in the training step — so this is a plain 32x32 LDS-tiled fp32 FMA kernel, not MFMA.
+// op1(i,l) = t1 ? mat1[l + ld1*i] : mat1[i + ld1*l];  op2(l,j) = t2 ? mat2[j + ld2*l] : mat2[l + ld2*j]   (column-major).
+// -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dot_generic_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c, int m, int n,
+                                                          int k, int ld1, int ld2, int t1, int t2, float beta, float alpha) {
+  __shared__ float As[32][33], Bs[32][33];   // As[l][i], Bs[l][j]
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int l0 = 0; l0 < k; l0 += 32) {
+    for (int r = ty; r < 32; r += 8) {
+      // tile element (l = l0 + r or l0 + tx, chosen so the global read is contiguous in tx)
+      if (t1) {   // contiguous in l
+        const int i = i0 + r, l = l0 + tx;
+        As[tx][r] = (i < m && l < k) ? a[(size_t)l + (size_t)ld1 * i] : 0.f;
+      } else {    // contiguous in i
+        const int i = i0 + tx, l = l0 + r;
+        As[r][tx] = (i < m && l < k) ? a[(size_t)i + (size_t)ld1 * l] : 0.f;
+      }
+      if (t2) {   // contiguous in j
+        const int j = j0 + tx, l = l0 + r;
+        Bs[r][tx] = (j < n && l < k) ? b[(size_t)j + (size_t)ld2 * l] : 0.f;
+      } else {    // contiguous in l
+        const int j = j0 + r, l = l0 + tx;
+        Bs[tx][r] = (j < n && l < k) ? b[(size_t)l + (size_t)ld2 * j] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int l = 0; l < 32; ++l) {
+      const float av = As[l][tx];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = fmaf(av, Bs[l][ty + 8 * q], acc[q]);
+    }
+    __syncthreads();
+  }
+  const int i = i0 + tx;
+  if (i < m) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = j0 + ty + 8 * q;
+      if (j < n) {
+        float* d = c + (size_t)i + (size_t)m * j;
+        *d = (beta != 0.f ? beta * (*d) : 0.f) + alpha * acc[q];
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
 // host-side dispatch
 // -------------------------------------------------------------------------------------------------
 namespace {
@@ -1440,9 +1492,17 @@ static int dot_impl(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target
   if (m != target->size[0] || n != target->size[1] || k1 != k2) return ERROR_INCOMPATIBLE_DIMENSIONS;
   if (target->is_trans) return ERROR_TRANSPOSED;
   const int K = k1;
+  if ((t1 && t2) || (!t1 && alpha != 1.0f)) {
+    // not one of fc_edge.cc's three shapes: the general kernel keeps dot()'s full contract; the fused extras have no such form
+    if (bias || relu || mask) return ERROR_UNSUPPORTED;
+    if (m == 0 || n == 0) return 0;
+    KernelTimer timer("dot_generic_kernel", "dot_generic", 2.0 * m * (double)n * K, 0.0);
+    hipLaunchKernelGGL(dot_generic_kernel, dim3(divup(m, 32), divup(n, 32)), dim3(256), 0, stream(), mat1->data_device, mat2->data_device,
+                       target->data_device, m, n, K, mat1->size[0], mat2->size[0], t1, t2, beta, alpha);
+    return launch_status();
+  }
   if (!t1) {
     // activations (m = N images) x weights
-    if (alpha != 1.0f) return ERROR_UNSUPPORTED;
     GGParams p{};
     p.src = mat1->data_device; p.dst = target->data_device; p.bias = bias ? bias->data_device : nullptr;
     p.A = mat2->data_device;
@@ -1482,7 +1542,7 @@ static int dot_impl(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target
     note_kernel("wg_kernel(fc TN)", 2.0 * m * (double)n * K, p.k_tiles * p.f_tiles, p.splits);
     return launch_status();
   }
-  return ERROR_UNSUPPORTED;  // T,T never occurs on the hot path
+  return ERROR_UNSUPPORTED;   // unreachable: every transpose combination is handled above
 }
 
 int dotBiasAct(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target, float beta, float alpha, int relu) {

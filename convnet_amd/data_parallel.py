@@ -38,13 +38,44 @@ def plan_buckets(slices, bucket_bytes):
     return buckets
 
 
+class _AbiDone:
+    """Done-marker of a bucket exchanged through the library's own entries: the done-events live inside the library, so a waiter
+    asks the library to make ITS current stream wait (Matrix.OnStream routes that to a side stream)."""
+
+    def __init__(self, slots):
+        self.slots = slots
+
+    def wait_library_stream(self):
+        from ._lib import lib
+        for s in self.slots:
+            if lib.convnet_hip_comm_wait(s) != 0:
+                raise RuntimeError("convnet_hip_comm_wait failed")
+
+
 class GradientExchange:
-    def __init__(self, bucket_bytes=8 << 20, overlap=True):
+    def __init__(self, bucket_bytes=8 << 20, overlap=True, transport="torch"):
+        """``transport``: "torch" — torch.distributed collectives (backend nccl = RCCL; gloo for tests) on a torch comm stream;
+        "abi" — the library's own exchange entries (include/convnet_hip.h convnet_hip_comm_*, csrc/comm.hip: RCCL through dlopen,
+        comm stream and events inside the library), the SAME path a C/C++ host drives; torch.distributed is
+        then used only to hand rank 0's RCCL id to the other ranks."""
         assert dist.is_initialized()
+        assert transport in ("torch", "abi")
         self.world_ = dist.get_world_size()
         self.rank_ = dist.get_rank()
         self.bucket_bytes_ = bucket_bytes
         self.overlap_ = overlap
+        self.transport_ = transport
+        self.avg_native_ = dist.get_backend() == "nccl"    # gloo has no ReduceOp.AVG (CPU or GPU tensors)
+        if transport == "abi":
+            import ctypes
+            from ._lib import lib
+            buf = ctypes.create_string_buffer(128)
+            if self.rank_ == 0 and lib.convnet_hip_comm_unique_id(buf) != 0:
+                raise RuntimeError("convnet_hip_comm_unique_id failed")
+            box = [buf.raw]
+            dist.broadcast_object_list(box, src=0)
+            if lib.convnet_hip_comm_init(self.rank_, self.world_, box[0]) != 0:
+                raise RuntimeError("convnet_hip_comm_init failed: " + lib.get_last_cuda_error().decode())
         self.comm_stream_ = None
         self.net_ = None
         self.bucket_of_ = {}
@@ -52,20 +83,37 @@ class GradientExchange:
         self.pending_ = {}
         self.done_events_ = {}
         self.ready_count_ = {}
+        self.next_slot_ = 0
 
     def Broadcast(self, mat, src=0):
         """ConvNet::Broadcast (src/convnet.cc:407-413) as one RCCL broadcast of the flat buffer."""
+        if self.transport_ == "abi":
+            from ._lib import lib
+            if lib.convnet_hip_comm_broadcast(mat.GetMat(), src) != 0:
+                raise RuntimeError("convnet_hip_comm_broadcast failed")
+            return
         dist.broadcast(mat.tensor(), src=src)
         torch.cuda.current_stream().synchronize() if mat.tensor().is_cuda else None
 
     def Register(self, net):
         self.net_ = net
-        # backward order = reverse topological order of the edges' source layers
+        # backward order = reverse topological order of the edges' source layers.  A slice shared through `tied_to` is final
+        # when its LAST sharer has run ComputeOuter, so the owner takes the position of that sharer.
         order = []
+        seen = {}
         for l in reversed(net.layers_):
             for e in l.outgoing_edge_:
-                if e in net.edge_slices_ and not e.IsBackPropBlocked():
-                    order.append(e)
+                if e.IsBackPropBlocked():
+                    continue
+                owner = e.tied_edge_ if e.IsTied() else e
+                if owner not in net.edge_slices_:
+                    continue
+                seen[owner] = seen.get(owner, 0) + 1
+                if seen[owner] == getattr(owner, "num_shares_", 1):
+                    order.append(owner)
+        missing = [e.GetName() for e in net.edge_slices_ if e not in order and not e.IsBackPropBlocked()]
+        if missing:
+            raise RuntimeError(f"gradient exchange: edges {missing} own parameters but never complete in backward order")
         slices = [(e, *net.edge_slices_[e]) for e in order]
         self.buckets_ = plan_buckets(slices, self.bucket_bytes_)
         self.bucket_of_ = {e: i for i, b in enumerate(self.buckets_) for e in b}
@@ -75,6 +123,7 @@ class GradientExchange:
     def StartStep(self):
         self.ready_count_ = {i: 0 for i in range(len(self.buckets_))}
         self.done_events_ = {}
+        self.next_slot_ = 0
 
     def _flat_ranges(self, bucket):
         """Merged contiguous [lo, hi) ranges of a bucket's slices in the flat buffer (slices are padded
@@ -98,6 +147,17 @@ class GradientExchange:
         self.ready_count_[i] += 1
         if self.ready_count_[i] < len(self.buckets_[i]):
             return
+        if self.transport_ == "abi":
+            from ._lib import lib
+            slots = []
+            for lo, hi in self._flat_ranges(self.buckets_[i]):
+                slot = self.next_slot_
+                self.next_slot_ += 1
+                if lib.convnet_hip_comm_allreduce_avg(self.net_.grad_parameters_.GetMat(), lo, hi - lo, slot) != 0:
+                    raise RuntimeError("convnet_hip_comm_allreduce_avg failed: " + lib.get_last_cuda_error().decode())
+                slots.append(slot)
+            self.done_events_[i] = _AbiDone(slots)
+            return
         flat = self.net_.grad_parameters_.tensor()
         parts = [flat[lo:hi] for lo, hi in self._flat_ranges(self.buckets_[i])]
         if self.comm_stream_ is not None and self.overlap_:
@@ -106,18 +166,21 @@ class GradientExchange:
             with torch.cuda.stream(self.comm_stream_):
                 self.comm_stream_.wait_event(ready)
                 for t in parts:
-                    dist.all_reduce(t, op=dist.ReduceOp.AVG)
+                    self._all_reduce_mean(t)
                 done = torch.cuda.Event()
                 done.record(self.comm_stream_)
             self.done_events_[i] = done
         else:
             for t in parts:
-                if t.is_cuda:
-                    dist.all_reduce(t, op=dist.ReduceOp.AVG)
-                else:   # gloo has no AVG
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                    t.div_(self.world_)
+                self._all_reduce_mean(t)
             self.done_events_[i] = None
+
+    def _all_reduce_mean(self, t):
+        if self.avg_native_:
+            dist.all_reduce(t, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t.div_(self.world_)
 
     def SumScalars(self, values):
         """ConvNet::Accumulate(train_error, MPITAG_TRAINERROR) (src/convnet.cc:939): the per-rank training-accuracy counts
@@ -143,7 +206,9 @@ class GradientExchange:
         ev = self.done_events_.get(i, "missing")
         if ev == "missing":
             raise RuntimeError(f"gradient bucket {i} of {edge.GetName()} was never exchanged")
-        if ev is not None:
+        if isinstance(ev, _AbiDone):
+            ev.wait_library_stream()      # the library's current stream = the compute stream
+        elif ev is not None:
             torch.cuda.current_stream().wait_event(ev)
             self.done_events_[i] = None
 

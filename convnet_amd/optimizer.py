@@ -1,8 +1,20 @@
 """Optimizers — mirror of src/optimizer.{h,cc} for the hot path (SGD + momentum, the only optimizer
 the target configs use; Adagrad/RMSProp/LBFGS are out of scope)."""
+import ctypes
 import math
 
+import numpy as np
+
 from .matrix import Matrix
+
+
+_libm = ctypes.CDLL("libm.so.6")
+_libm.expf.restype, _libm.expf.argtypes = ctypes.c_float, [ctypes.c_float]
+
+
+def _expf(x):
+    """glibc's expf — the function the reference's `exp(float)` resolves to (numpy's float32 exp is a different implementation)."""
+    return np.float32(_libm.expf(float(x)))
 
 
 class Optimizer:
@@ -38,23 +50,27 @@ class Optimizer:
             parameter.NormLimitByAxis(1, self.weight_norm_limit_, False)
 
     def GetDecayedEpsilon(self):
-        # src/optimizer.cc:83-104
-        eps = self.epsilon_
+        # src/optimizer.cc:83-104, evaluated in the reference's types: `float f`, expf, float arithmetic; only EXPONENTIAL_STEP
+        # goes through double (C++11 pow(float, int) promotes both) and is rounded to float once.  Intentional deviation: for decay
+        # type NONE with a timescale > 0 the reference's guard (it compares the TIMESCALE with the enum NONE, :85-86) enters the
+        # branch and exits with "Unknown epsilon decay rule"; here that combination just means "no decay".
+        f32 = np.float32
+        eps = f32(self.epsilon_)
         ts = self.epsilon_decay_timescale_
         if ts > 0 and self.epsilon_decay_type_ != "NONE":
-            f = float(self.step_) / ts
+            f = f32(f32(self.step_) / f32(ts))
             t = self.epsilon_decay_type_
             if t == "EXPONENTIAL":
-                eps = self.epsilon_ * math.exp(-f)
+                eps = f32(f32(self.epsilon_) * _expf(-f))
             elif t == "INVERSE_T":
-                eps = self.epsilon_ / (1 + f)
+                eps = f32(f32(self.epsilon_) / f32(f32(1) + f))
             elif t == "LINEAR":
-                eps = self.epsilon_ * (1 - f) + self.minimum_epsilon_ * f if f < 1 else self.minimum_epsilon_
+                eps = f32(f32(f32(self.epsilon_) * f32(f32(1) - f)) + f32(f32(self.minimum_epsilon_) * f)) if f < 1 else f32(self.minimum_epsilon_)
             elif t == "EXPONENTIAL_STEP":
-                eps = self.epsilon_ * math.pow(self.decay_factor_, self.step_ // ts)
+                eps = f32(float(f32(self.epsilon_)) * math.pow(float(f32(self.decay_factor_)), self.step_ // ts))
             else:
                 raise SystemExit("Unknown epsilon decay rule.")
-        return max(eps, self.minimum_epsilon_)
+        return float(max(eps, f32(self.minimum_epsilon_)))
 
     def NotifyStart(self, parameter):
         pass
@@ -107,10 +123,11 @@ class SGDOptimizer(Optimizer):
         file.WriteHDF5IntAttr(f"{prefix}_step", self.step_)
 
     def GetMomentum(self):
-        # src/optimizer.cc:158-165
+        # src/optimizer.cc:158-165 in float, like the reference (expf of a float argument)
+        f32 = np.float32
         if self.momentum_transition_timescale_ > 0:
-            return self.initial_momentum_ + (self.final_momentum_ - self.initial_momentum_) * \
-                (1 - math.exp(-float(self.step_) / self.momentum_transition_timescale_))
+            x = f32(-f32(self.step_) / f32(self.momentum_transition_timescale_))
+            return float(f32(f32(self.initial_momentum_) + f32(f32(f32(self.final_momentum_) - f32(self.initial_momentum_)) * f32(f32(1) - _expf(x)))))
         return self.final_momentum_
 
     def NotifyStart(self, parameter):

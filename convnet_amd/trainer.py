@@ -112,6 +112,8 @@ class TrainLoopMixin:
             lr_reduce_layer_id = names.index(m.reduce_lr_layer_name)
         if not hasattr(self, "lr_reduce_counter_"):
             self.lr_reduce_counter_ = 0
+        if self.is_root_ and checkpoint and not m.timestamp:
+            self.TimestampModel()                 # src/convnet.cc:875
         history = {"train": [], "val": [], "lr_reductions": 0}
         train_error, val_error = None, []
         dont_reduce_lr = 0
@@ -124,7 +126,7 @@ class TrainLoopMixin:
             if this_err is not None:             # unfused: per-step host value; fused: read every print_after below
                 train_error = this_err if train_error is None else [a + b for a, b in zip(train_error, this_err)]
             if print_after > 0 and (i + 1) % print_after == 0:
-                if self.fused:
+                if self.fused and train_error is None:    # fused softmax output: the count lives on the device
                     train_error = [self.ReadCorrectCount()]
                 if self.exchange_ is not None and hasattr(self.exchange_, "SumScalars"):
                     train_error = self.exchange_.SumScalars(train_error)

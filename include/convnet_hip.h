@@ -197,7 +197,8 @@ void ResponseNormCrossMapUndo(cudamat* outGrads, cudamat* inputs, cudamat* acts,
 
 /* ---- dense ops (cudamat.cuh:170-263) ------------------------------------------------------------- */
 /* target = beta*target + alpha*op(mat1)*op(mat2), op = transpose iff is_trans (cudamat.cu:2130-2152).
- * fc_edge.cc's three uses (NT fwd, NN dgrad, TN wgrad) run on fp32 MFMA; TT is ERROR_UNSUPPORTED. */
+ * fc_edge.cc's three uses (NT fwd, NN dgrad, TN wgrad, alpha on the TN side) run on fp32 MFMA; the remaining cases of the
+ * reference's contract (T,T; alpha != 1 with a non-transposed mat1) run on a plain LDS-tiled fp32 kernel. */
 int dot(cudamat* mat1, cudamat* mat2, cudamat* target, float beta, float alpha);
 float vdot(cudamat* mat1, cudamat* mat2, int* err_code);
 int add_row_vec(cudamat* mat, cudamat* vec, cudamat* target);
@@ -299,9 +300,35 @@ typedef struct ConvnetHipKernelInfo {
 void convnet_hip_last_kernel_info(ConvnetHipKernelInfo* out);
 /* Per-launch HIP-event timing on the library stream (used by bench.py's roofline leg).  While enabled
  * every conv/FC/pool/norm launch is bracketed by two hipEventRecord calls; the report synchronises,
- * aggregates by (kernel, op) into text lines "kernel|op|launches|total_ms|total_flops|total_bytes". */
+ * aggregates by (kernel, op) into text lines "kernel|op|launches|total_ms|total_flops|total_bytes|total_executed_flops"
+ * (flops = algorithmic work; executed = MFMA work issued, larger for dgrad gathers that run border taps on the zero page). */
 void convnet_hip_profile_enable(int on);
 size_t convnet_hip_profile_report(char* buf, size_t cap);
+
+/* ---- data-parallel gradient exchange (csrc/comm.hip): replaces ConvNet::Accumulate + ConvNet::Broadcast ------------------
+ * Reference (src/convnet.cc:407-450, behind USE_MPI): after Bprop the whole flat gradient goes device -> host, rank 0
+ * MPI_Recv-sums every rank's copy, divides by num_processes_ (:431), copies it back and MPI_Bcasts it; UpdateWeights (:440-450)
+ * then steps every edge.  Here: one process per GPU, RCCL over xGMI, every slice (or bucket of slices) of the flat gradient is
+ * all-reduced on a communication stream from the moment it is final, and the compute stream waits — on the device, not the
+ * host — right before the optimizer step that consumes it.  librccl is dlopen'ed by convnet_hip_comm_init.
+ *
+ *   rank 0:   convnet_hip_comm_unique_id(id);  ship the 128 bytes to the other ranks (MPI_Bcast / a file / a socket)
+ *   all:      convnet_hip_comm_init(rank, nranks, id);  convnet_hip_comm_broadcast(&parameters, 0);      // convnet.cc:309
+ *   Bprop(output, input, edge), after edge.ComputeOuter:  convnet_hip_comm_allreduce_avg(&grad_parameters, off, n, slot);
+ *   UpdateWeights, before edge->UpdateWeights():          convnet_hip_comm_wait(slot);
+ * `slot` (0..255) names the done-event of one post; it stays waitable until the same slot is posted again.
+ * grad[off .. off+n) becomes sum over ranks / nranks (true division, as :431).  Returns 0 or a cudamat error code
+ * (get_last_cuda_error() has the RCCL text). */
+#define CONVNET_HIP_COMM_ID_BYTES 128
+int convnet_hip_comm_unique_id(char* id_out);
+int convnet_hip_comm_init(int rank, int nranks, const char* id_in);
+int convnet_hip_comm_rank(void);
+int convnet_hip_comm_size(void);
+int convnet_hip_comm_broadcast(cudamat* mat, int root);
+int convnet_hip_comm_allreduce_avg(cudamat* flat, size_t offset, size_t count, int slot);
+int convnet_hip_comm_wait(int slot);
+int convnet_hip_comm_sync(void);      /* host-blocking drain of the communication stream */
+int convnet_hip_comm_destroy(void);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <ctime>
 #include <fstream>
+#include <map>
 #include <iostream>
 #include <new>
 #include <sstream>
@@ -351,6 +352,140 @@ void seam_host_grad_check(const char* model_pbtxt, int batch_size, const char* o
   gc.AllocateMemory(false);
   gc.Run(output_h5);
 }
+
+#ifdef USE_CUDA
+}  // extern "C"  (closed around the class below)
+
+// ---- data-parallel host on the library's exchange entries (include/convnet_hip.h, csrc/comm.hip) --------------------------------
+// What a maintainer of the reference adds to train_convnet_data_parallel, shown here as a SUBCLASS so that src/convnet.cc stays
+// untouched (INTEGRATION.md §4 prints the same thing as a patch): ConvNet::Bprop(output, input, edge) and ConvNet::UpdateWeights
+// are virtual (src/convnet.h:125,136).  Every edge's slice of the flat gradient is posted for all-reduce the moment its
+// ComputeOuter has run (slices coalesced into buckets of >= bucket_bytes), and UpdateWeights waits — on the device — for a slice's
+// bucket right before that edge's optimizer step, instead of Accumulate + Broadcast of the whole buffer through the host
+// (src/convnet.cc:407-450).  The prototypes are repeated because the reference's cudamat.cuh and this repo's convnet_hip.h both
+// define struct cudamat (identically).
+extern "C" {
+int convnet_hip_comm_unique_id(char* id_out);
+int convnet_hip_comm_init(int rank, int nranks, const char* id_in);
+int convnet_hip_comm_broadcast(cudamat* mat, int root);
+int convnet_hip_comm_allreduce_avg(cudamat* flat, size_t offset, size_t count, int slot);
+int convnet_hip_comm_wait(int slot);
+int convnet_hip_comm_sync(void);
+int convnet_hip_comm_destroy(void);
+}
+
+namespace {
+// Matrix::GetMat() is protected (src/matrix.h:217).  The real integration adds three public Matrix methods that forward to the
+// exchange entries; this shim must leave src/matrix.h untouched, so it reaches the cudamat through a derived
+// accessor instead.
+struct MatAccess : public Matrix {
+  static cudamat* Of(Matrix& m) { return static_cast<MatAccess&>(m).GetMat(); }
+};
+
+class SeamDPNet : public SeamNet {
+ public:
+  SeamDPNet(const string& model_file, size_t bucket_bytes) : SeamNet(model_file), bucket_floats_(bucket_bytes / sizeof(float)) {}
+  void BroadcastParameters() { CheckRc(convnet_hip_comm_broadcast(MatAccess::Of(parameters_), 0)); }   // src/convnet.cc:309
+  int Buckets() const { return next_slot_; }
+
+ protected:
+  void Bprop(Layer& output, Layer& input, Edge& edge) override {
+    ConvNet::Bprop(output, input, edge);
+    EdgeWithWeight* e = dynamic_cast<EdgeWithWeight*>(&edge);
+    if (e == NULL || edge.IsBackPropBlocked()) return;
+    if (edge.IsTied()) {
+      std::cerr << "SeamDPNet: tied edges are not handled by this demonstration host" << std::endl;
+      exit(1);
+    }
+    const size_t off = MatAccess::Of(e->GetGradWeight())->data_device - MatAccess::Of(grad_parameters_)->data_device;
+    const size_t n = (edge.GetParameterMemoryRequirement() + 127) / 128 * 128;   // the slice with its alignment pad (convnet.cc:279)
+    if (open_ && off + n != lo_) Flush();          // not adjacent (a DAG): close the bucket
+    if (!open_) { hi_ = off + n; open_ = true; }
+    lo_ = off;                                     // backward order walks the flat buffer downwards
+    pending_.push_back(e);
+    if (hi_ - lo_ >= bucket_floats_) Flush();
+  }
+  void UpdateWeights() override {
+    Flush();
+    for (Edge* ed : edges_) {
+      if (ed->IsBackPropBlocked()) continue;
+      std::map<Edge*, int>::iterator it = slot_of_.find(ed);
+      if (it != slot_of_.end()) CheckRc(convnet_hip_comm_wait(it->second));
+      ed->UpdateWeights();
+    }
+    slot_of_.clear();
+    next_slot_ = 0;
+  }
+
+ private:
+  void Flush() {
+    if (!open_) return;
+    size_t hi = hi_;
+    const size_t total = (size_t)grad_parameters_.GetRows() * grad_parameters_.GetCols();
+    if (hi > total) hi = total;
+    CheckRc(convnet_hip_comm_allreduce_avg(MatAccess::Of(grad_parameters_), lo_, hi - lo_, next_slot_));
+    for (Edge* e : pending_) slot_of_[e] = next_slot_;
+    pending_.clear();
+    ++next_slot_;
+    open_ = false;
+  }
+  static void CheckRc(int rc) {
+    if (rc != 0) {
+      std::cerr << "convnet_hip_comm error " << rc << std::endl;
+      exit(1);
+    }
+  }
+  size_t bucket_floats_, lo_ = 0, hi_ = 0;
+  bool open_ = false;
+  int next_slot_ = 0;
+  vector<Edge*> pending_;
+  std::map<Edge*, int> slot_of_;
+};
+}  // namespace
+
+extern "C" {
+
+// `steps` x TrainOneBatch of the data-parallel host above as rank `rank` of `nranks` (id: the 128-byte RCCL id from rank 0's
+// seam_host_dp_unique_id; with nranks == 1 the id may be NULL and is created here).  Returns the parameter count; *buckets_out =
+// buckets posted in the last step.
+long seam_host_train_dp(const char* model_pbtxt, const char* data_pbtxt, int steps, const float* params_in, float* params_out, long params_cap,
+                        int rank, int nranks, const char* id, long bucket_bytes, int* buckets_out) {
+  setup_device();
+  char local_id[128];
+  if (id == NULL) {
+    if (nranks != 1 || convnet_hip_comm_unique_id(local_id) != 0) return -1;
+    id = local_id;
+  }
+  if (convnet_hip_comm_init(rank, nranks, id) != 0) return -2;
+  long n = 0;
+  {
+    SeamDPNet net(model_pbtxt, (size_t)bucket_bytes);
+    net.SetupDataset(data_pbtxt);
+    net.AllocateMemory(false);
+    Matrix& P = net.Params();
+    n = (long)P.GetRows() * P.GetCols();
+    if (params_in) {
+      memcpy(P.GetHostData(), params_in, sizeof(float) * n);
+      P.CopyToDevice();
+    }
+    net.BroadcastParameters();
+    vector<float> err;
+    int buckets = 0;
+    for (int i = 0; i < steps; ++i) {
+      net.OneStep(err);
+      buckets = net.Buckets();
+    }
+    (void)buckets;
+    convnet_hip_comm_sync();
+    P.CopyToHost();
+    if (params_out && n <= params_cap) memcpy(params_out, P.GetHostData(), sizeof(float) * n);
+  }
+  convnet_hip_comm_destroy();
+  return n;
+}
+
+int seam_host_dp_unique_id(char* id_out) { return convnet_hip_comm_unique_id(id_out); }
+#endif  // USE_CUDA
 
 // run_grad_check on a FIXED point: GradChecker::Run (src/grad_check.cc:77-140) with its random fill of the inputs and labels
 // replaced by the data shim's batch 0 and the parameters supplied by the caller, so the reference's CPU build and its build on

@@ -134,6 +134,21 @@ class RefHost:
         self.lib.seam_host_grad_check(str(model).encode(), batch, str(out_h5).encode())
 
 
+    def train_dp(self, model, data, steps, params, rank=0, nranks=1, comm_id=None, bucket_bytes=8 << 20):
+        """`steps` x TrainOneBatch of the data-parallel subclass host (seam_host.cc SeamDPNet: gradient slices posted to the
+        library's RCCL exchange entries from Bprop, waited for in UpdateWeights) — libref_host_hip.so only."""
+        fn = self.lib.seam_host_train_dp
+        fn.restype = ctypes.c_long
+        fn.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int,
+                       ctypes.c_char_p, ctypes.c_long, ctypes.c_void_p]
+        p = np.ascontiguousarray(params, np.float32)
+        out = np.zeros_like(p)
+        buckets = ctypes.c_int(0)
+        n = fn(str(model).encode(), str(data).encode(), steps, p.ctypes.data, out.ctypes.data, out.size, rank, nranks, comm_id, bucket_bytes,
+               ctypes.byref(buckets))
+        assert n == out.size, n
+        return out
+
     def grad_check_fixed(self, model, data, params, out_h5):
         """GradChecker on the data shim's batch 0 at the given parameters (seam_host.cc SeamGradChecker::RunFixed): the reference's
         own compiled pass/fail verdicts, [(weights_passed, bias_passed)] per grad_check edge in edge order; arrays go to `out_h5`."""

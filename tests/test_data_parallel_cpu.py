@@ -30,14 +30,21 @@ def _free_port():
 
 
 class _FakeEdge:
-    def __init__(self, name):
+    def __init__(self, name, tied_to=None):
         self.name = name
+        self.tied_edge_ = tied_to
+        self.num_shares_ = 1
+        if tied_to is not None:
+            tied_to.num_shares_ += 1
 
     def GetName(self):
         return self.name
 
     def IsBackPropBlocked(self):
         return False
+
+    def IsTied(self):
+        return self.tied_edge_ is not None
 
 
 class _FakeLayer:
@@ -115,3 +122,27 @@ def test_gradient_exchange_two_ranks_gloo(bucket_bytes):
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, bucket_bytes, out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def test_register_places_a_tied_owner_where_its_last_sharer_completes():
+    """an edge tied to another one owns no slice; the owner's slice is final only after the LAST sharer's
+    ComputeOuter in backward order — the owner must be bucketed there, not at its own position."""
+    class Net:
+        pass
+    owner, mid = _FakeEdge("a:b"), _FakeEdge("b:c")
+    tied = _FakeEdge("c:d", tied_to=owner)          # nearer the output: runs FIRST in backward order
+    net = Net()
+    net.layers_ = [_FakeLayer([owner]), _FakeLayer([mid]), _FakeLayer([tied]), _FakeLayer([])]
+    net.edge_slices_ = {owner: (0, 200), mid: (256, 1000)}
+    net.grad_parameters_ = _FakeFlat(torch.zeros(1280))
+    ex = GradientExchange.__new__(GradientExchange)
+    ex.bucket_bytes_, ex.comm_stream_ = 1, None
+    ex.Register(net)
+    assert ex.buckets_ == [[mid], [owner]]
+    # owner nearer the output than its sharer: final at the sharer's position (last in backward order)
+    owner2, mid2 = _FakeEdge("c:d"), _FakeEdge("b:c")
+    tied2 = _FakeEdge("a:b", tied_to=owner2)
+    net.layers_ = [_FakeLayer([tied2]), _FakeLayer([mid2]), _FakeLayer([owner2]), _FakeLayer([])]
+    net.edge_slices_ = {owner2: (1280, 130), mid2: (256, 1000)}
+    ex.Register(net)
+    assert ex.buckets_ == [[mid2], [owner2]]

@@ -160,6 +160,22 @@ def test_fc_dot_three_forms_vs_oracle(hip, N, D, F):
         assert rel_err(hip.dot(dy, x, t0.copy(), beta, 1.0 / N, True, False), oracle.port.dot(dy, x, t0.copy(), beta, 1.0 / N, True, False)) < TOL
 
 
+@pytest.mark.parametrize("m,n,k", [(37, 50, 61), (128, 96, 256), (5, 3, 2)])
+def test_dot_full_contract_all_transposes_and_alpha(hip, m, n, k):
+    """dot's whole contract (cudamat.cu:2130-2152: every transpose combination, any alpha and beta), not only fc_edge.cc's three
+    uses: T,T and alpha != 1 on the N,x side run on the library's general kernel."""
+    rng = np.random.default_rng(23)
+    for ta in (False, True):
+        for tb in (False, True):
+            a = rnd(rng, (m, k) if ta else (k, m))      # numpy (cols, rows) view of a column-major (rows, cols) matrix
+            b = rnd(rng, (k, n) if tb else (n, k))
+            for beta, alpha in ((0.0, 1.0), (0.5, -1.75), (1.0, 0.3)):
+                t0 = rnd(rng, (n, m))
+                got = hip.dot(a, b, t0.copy(), beta, alpha, ta, tb)
+                want = oracle.port.dot(a, b, t0.copy(), beta, alpha, ta, tb)
+                assert rel_err(got, want) < TOL, (ta, tb, beta, alpha, rel_err(got, want))
+
+
 def test_linearity_and_adjointness_at_full_alexnet_conv3_size(hip):
     """Size-independent properties at BASELINE's full layer size (N=256), where the CPU oracle would
     take minutes: <conv(x,w), dy> == <x, convT(dy,w)> == <w, wgrad(x,dy)> (the three kernels are

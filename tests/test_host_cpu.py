@@ -76,6 +76,7 @@ def test_mnist_and_vgg_graphs():
 
 
 def test_sgd_schedules():
+    import numpy as np
     c = pbtxt.Optimizer()
     c.epsilon, c.initial_momentum, c.final_momentum, c.momentum_transition_timescale = 0.01, 0.5, 0.9, 2000
     o = SGDOptimizer.__new__(SGDOptimizer)
@@ -85,14 +86,15 @@ def test_sgd_schedules():
     o.step_ = 0
     assert o.GetMomentum() == 0.5
     o.step_ = 2000
-    assert abs(o.GetMomentum() - (0.5 + 0.4 * (1 - math.exp(-1)))) < 1e-12                    # src/optimizer.cc:158-165
+    assert abs(o.GetMomentum() - (0.5 + 0.4 * (1 - math.exp(-1)))) < 1e-7                     # src/optimizer.cc:158-165, in float
+    assert o.GetMomentum() == float(np.float32(o.GetMomentum()))                                # ... and representable as one
     c2 = pbtxt.Optimizer()
     c2.epsilon, c2.epsilon_decay, c2.epsilon_decay_timescale, c2.minimum_epsilon = 1.0, "INVERSE_T", 10, 0.2
     Optimizer.__init__(o, c2)
     o.step_ = 10
     assert o.GetDecayedEpsilon() == 0.5
     o.step_ = 1000
-    assert o.GetDecayedEpsilon() == 0.2
+    assert o.GetDecayedEpsilon() == float(np.float32(0.2))   # float minimum_epsilon_
 
 
 def test_hdf5_io_layout_and_reference_written_file(tmp_path):
