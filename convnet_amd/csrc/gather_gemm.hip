@@ -34,6 +34,23 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int BK = 16;  // reduction depth per LDS stage (gg_kernel)
 
+// Diagnostic build only (tools/gg_trace.cc compiles this file with -DCONVNET_GG_TRACE; the library never does): per-block phase
+// timing of gg_kernel's main loop with s_memtime — where a chunk's wall time goes (staging issue / MFMA phase / closing wait +
+// barrier), how the two co-resident blocks of a CU share the matrix pipe, and how far block end times spread.
+#ifdef CONVNET_GG_TRACE
+constexpr bool kTrace = true;
+__device__ unsigned long long* g_gg_trace = nullptr;   // 16 words per (block, wave)
+#else
+constexpr bool kTrace = false;
+#endif
+__device__ __forceinline__ unsigned long long trace_clock() {
+#ifdef CONVNET_GG_TRACE
+  return __builtin_amdgcn_s_memtime();
+#else
+  return 0;
+#endif
+}
+
 struct GGParams {
   const float* A;
   const float* src;
@@ -249,6 +266,8 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
   const int li = lane & 31, lh = lane >> 5;
   const int r0 = row_tile * ROWS;
   const int N = p.N;
+  unsigned long long tr_begin_k = 0;
+  if constexpr (kTrace) tr_begin_k = trace_clock();
 
   // ---- per-thread constants for the B (source) staging slots -----------------------------------
   // VEC (direct-to-LDS) lays the B stage out k-row major, [krow][wave-column][image]: one wave instruction (64 lanes x
@@ -496,10 +515,15 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
   constexpr bool SPREAD = false && GLDS_A && GLDS_B;
   constexpr bool PRIO = true;
   constexpr int NP = NA + NB, PPS = (NP + BK / 2 - 1) / (BK / 2);
+  unsigned long long tr_begin = tr_begin_k, tr_loop = 0, tr_stage = 0, tr_mfma = 0, tr_sync = 0, tr_min_m = ~0ull, tr_max_m = 0, tr_min_t = ~0ull, tr_max_t = 0;
+  if constexpr (kTrace) tr_loop = trace_clock();
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
     const bool more = c + 1 < nchunks;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+    if constexpr (kTrace) tr0 = trace_clock();
     if (!SPREAD && more) fetch(kbeg + (c + 1) * BK, buf ^ 1);
+    if constexpr (kTrace) tr1 = trace_clock();
     const float* as = As + buf * A_STAGE;
     const float* bs = Bs + buf * B_STAGE + (KM ? wc * CW : wc * BK * CW) + NTC * li;
     if (!A_KCONTIG) {
@@ -562,9 +586,28 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
         }
       }
     }
+    if constexpr (kTrace) tr2 = trace_clock();
     if (c + 1 < nchunks) stash(buf ^ 1);
     __syncthreads();
+    if constexpr (kTrace) {
+      const unsigned long long tr3 = trace_clock();
+      tr_stage += tr1 - tr0; tr_mfma += tr2 - tr1; tr_sync += tr3 - tr2;
+      tr_min_m = min(tr_min_m, tr2 - tr1); tr_max_m = max(tr_max_m, tr2 - tr1);
+      tr_min_t = min(tr_min_t, tr3 - tr0); tr_max_t = max(tr_max_t, tr3 - tr0);
+    }
   }
+#ifdef CONVNET_GG_TRACE
+  const unsigned long long tr_loop_end = trace_clock();
+  auto trace_out = [&](unsigned long long t_end) {
+    if (g_gg_trace && lane == 0) {
+      unsigned long long* o = g_gg_trace + 16 * ((size_t)blockIdx.x * (NT / 64) + wave);
+      o[0] = __builtin_amdgcn_s_getreg((15 << 11) | 4);   // HW_ID low 16 bits: wave slot, SIMD, CU
+      o[1] = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID
+      o[2] = tr_begin; o[3] = t_end; o[4] = (unsigned long long)nchunks; o[5] = tr_stage; o[6] = tr_mfma; o[7] = tr_sync;
+      o[8] = tr_min_m; o[9] = tr_max_m; o[10] = tr_min_t; o[11] = tr_max_t; o[12] = tr_loop; o[13] = tr_loop_end; o[14] = (unsigned long long)L;
+    }
+  };
+#endif
 
   // ---- epilogue ---------------------------------------------------------------------------------
   if (tsplit >= 0) {   // one K-range of a tail tile: raw sums, register order (gg_tail_fix_kernel finishes the tile)
@@ -581,6 +624,9 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
     return;
   }
   gg_epilogue<WR, WC, MT, CW, VEC>(p, acc, row_tile, col_tile, split, pncols, pGX, pdy0, pdx0);
+#ifdef CONVNET_GG_TRACE
+  trace_out(trace_clock());
+#endif
 }
 
 // Sums the tail_splits partial tiles of one tail tile in fixed order and applies the normal epilogue.
@@ -1308,6 +1354,12 @@ void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* tar
 }  // namespace chip
 
 using namespace chip;
+
+#ifdef CONVNET_GG_TRACE
+extern "C" void convnet_hip_debug_set_gg_trace(unsigned long long* dev_buf) {
+  CHIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(chip::g_gg_trace), &dev_buf, sizeof dev_buf));
+}
+#endif
 
 extern "C" {
 

@@ -403,12 +403,25 @@ __device__ __forceinline__ void rn_stage(const float* __restrict__ g, float* __r
   }
 }
 
+// Block -> location-tile map of the LDS response-norm kernels.  A tile is LT consecutive locations = LT*4 bytes per channel row;
+// with LT = 16 that is HALF a 128-byte line, and the hardware puts consecutive blocks on different XCDs (block b on XCD b%8), so
+// neighbouring tiles fetched every line into two L2s (measured on rnorm1's undo: 1.19 GB fetched for 0.59 GB of input).  Each XCD
+// therefore takes a contiguous run of tiles.  `tiles` = real tile count; the grid is rounded up to a multiple of 8.
+__device__ __forceinline__ long rn_tile(unsigned tiles, bool xcd) {
+  if (!xcd) return blockIdx.x < tiles ? (long)blockIdx.x : -1;
+  const unsigned per = (tiles + 7) >> 3;
+  const unsigned L = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  return L < tiles ? (long)L : -1;
+}
+
 template <int LT>
 __global__ void rnorm_fwd_lds_kernel(const float* __restrict__ in, float* __restrict__ out, size_t locs, int C, int sizeF, float addScale,
-                                     float powScale, bool blocked, bool vec, bool relu) {
+                                     float powScale, bool blocked, bool vec, bool relu, unsigned tiles, bool xcd) {
   extern __shared__ __attribute__((aligned(16))) float rn_smem[];
   float* xs = rn_smem;   // [C][LT]
-  const size_t l0 = (size_t)blockIdx.x * LT;
+  const long tile = rn_tile(tiles, xcd);
+  if (tile < 0) return;
+  const size_t l0 = (size_t)tile * LT;
   rn_stage<LT>(in, xs, locs, l0, C, vec);
   __syncthreads();
   const int l = threadIdx.x % LT, g = threadIdx.x / LT, G = blockDim.x / LT;
@@ -437,12 +450,14 @@ __global__ void rnorm_fwd_lds_kernel(const float* __restrict__ in, float* __rest
 
 template <int LT>
 __global__ void rnorm_undo_lds_kernel(const float* __restrict__ dout, const float* __restrict__ in, float* __restrict__ out, size_t locs, int C,
-                                      int sizeF, float addScale, float powScale, bool blocked, bool vec) {
+                                      int sizeF, float addScale, float powScale, bool blocked, bool vec, unsigned tiles, bool xcd) {
   extern __shared__ __attribute__((aligned(16))) float rn_smem[];
   float* xs = rn_smem;            // [C][LT] inputs
   float* ds = xs + C * LT;        // [C][LT] out-grads, then "scaled" = dout * den^(b/(b+1))
   float* ps_ = ds + C * LT;       // [C][LT] prod   = dout * in * den,  den = (1 + a*S)^(-b-1)
-  const size_t l0 = (size_t)blockIdx.x * LT;
+  const long tile = rn_tile(tiles, xcd);
+  if (tile < 0) return;
+  const size_t l0 = (size_t)tile * LT;
   rn_stage<LT>(in, xs, locs, l0, C, vec);
   rn_stage<LT>(dout, ds, locs, l0, C, vec);
   __syncthreads();
@@ -640,8 +655,10 @@ static void rnorm_fwd_impl(cudamat* images, cudamat* targets, int numFilters, in
     if (const char* f = getenv("CONVNET_RNORM_FWD_LT")) LT = atoi(f);   // tuning knob (tools/pool_bench.py)
     if (LT) {   // LDS-tiled, read-once/write-once
       const size_t smem = sizeof(float) * (size_t)C * LT;
-      const dim3 grid((unsigned)((locs + LT - 1) / LT)), block(256);
-#define RN_FWD(L) hipLaunchKernelGGL(rnorm_fwd_lds_kernel<L>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec, relu)
+      static const bool xcd = getenv("CONVNET_RNORM_NO_XCD") == nullptr;   // A/B switch for the XCD-contiguous tile order
+      const unsigned tiles = (unsigned)((locs + LT - 1) / LT);
+      const dim3 grid(xcd ? (tiles + 7) / 8 * 8 : tiles), block(256);
+#define RN_FWD(L) hipLaunchKernelGGL(rnorm_fwd_lds_kernel<L>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec, relu, tiles, xcd)
       if (LT == 64) RN_FWD(64);
       else if (LT == 32) RN_FWD(32);
       else if (LT == 16) RN_FWD(16);
@@ -680,14 +697,16 @@ void ResponseNormCrossMapUndoGemm(cudamat* outGrads, cudamat* inputs, cudamat* t
       const bool vec = locs % 4 == 0 && a16(outGrads->data_device) && a16(inputs->data_device) && a16(targets->data_device);
       KernelTimer timer("rnorm_undo_kernels", "rnorm_undo", 0.0, 12.0 * total);
       const size_t smem = sizeof(float) * 3 * (size_t)C * LT;
-      const dim3 grid((unsigned)((locs + LT - 1) / LT)), block(256);
+      static const bool xcd = getenv("CONVNET_RNORM_NO_XCD") == nullptr;   // A/B switch for the XCD-contiguous tile order
+      const unsigned tiles = (unsigned)((locs + LT - 1) / LT);
+      const dim3 grid(xcd ? (tiles + 7) / 8 * 8 : tiles), block(256);
       CHIP_REQUIRE(smem <= 160 * 1024);
 #define RN_UNDO(L)                                                                                                              \
   do {                                                                                                                          \
     if (smem > 64 * 1024)   /* >64 KiB of dynamic LDS needs an explicit opt-in */                                                \
       CHIP_CHECK(hipFuncSetAttribute((const void*)rnorm_undo_lds_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
     hipLaunchKernelGGL(rnorm_undo_lds_kernel<L>, grid, block, smem, stream(), outGrads->data_device, inputs->data_device,       \
-                       targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec);                                  \
+                       targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec, tiles, xcd);                      \
   } while (0)
       if (LT == 64) RN_UNDO(64);
       else if (LT == 32) RN_UNDO(32);
