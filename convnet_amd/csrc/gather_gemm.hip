@@ -38,7 +38,7 @@ constexpr int BK = 16;  // reduction depth per LDS stage (gg_kernel)
 // timing of gg_kernel's main loop with s_memtime — where a chunk's wall time goes (staging issue / MFMA phase / closing wait +
 // barrier), how the two co-resident blocks of a CU share the matrix pipe, and how far block end times spread.
 #ifdef CONVNET_GG_TRACE
-constexpr bool kTrace = true;
+constexpr bool kTrace = CONVNET_GG_TRACE >= 2;          // 2: per-chunk phases (perturbs the loop by ~20 %); 1: block-level times only
 __device__ unsigned long long* g_gg_trace = nullptr;   // 16 words per (block, wave)
 #else
 constexpr bool kTrace = false;
@@ -82,6 +82,8 @@ struct GGParams {
   // the normal epilogue.  Block b: XCD k = b & 7 does its run of tail_tf8 full tiles, then its tail_tt8 tail pieces.
   int tail_first, tail_splits, tail_cps, tail_tf8, tail_tt8;
   float* tail_partial;
+  int prio;            // issue priority scheme of the main loop (gg_prio_mode())
+  int ablate;          // DIAGNOSTIC (CONVNET_GG_ABLATE, wrong results): 1 = no staging after the second chunk; 2 = every staging load reads the zero page
 };
 
 // A strided dgrad is one gather-GEMM per stride class (conv_down_impl); the classes differ only in the fields
@@ -267,7 +269,9 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
   const int r0 = row_tile * ROWS;
   const int N = p.N;
   unsigned long long tr_begin_k = 0;
-  if constexpr (kTrace) tr_begin_k = trace_clock();
+#ifdef CONVNET_GG_TRACE
+  tr_begin_k = trace_clock();
+#endif
 
   // ---- per-thread constants for the B (source) staging slots -----------------------------------
   // VEC (direct-to-LDS) lays the B stage out k-row major, [krow][wave-column][image]: one wave instruction (64 lanes x
@@ -366,12 +370,12 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
   // scalars for the staging lambdas (they capture these, not the parameter struct)
   const float* const q_zero = p.zero;
   const float* const q_src = p.src;
-  const int q_lda = p.lda, q_dir = p.dir, q_SH = p.SH, q_SW = p.SW;
+  const int q_lda = p.lda, q_dir = p.dir, q_SH = p.SH, q_SW = p.SW, q_ablate = p.ablate;
   const float* const a_end = pA + (size_t)p.lda * kend;   // r-contiguous A: first address of row k = kend
   auto fetch_a_piece = [&](auto IT, int buf) __attribute__((always_inline)) {
     constexpr int it = decltype(IT)::value;
     const float* const ap = a_ptr[it];   // rvalues: a conditional on two lvalues selects an ADDRESS and keeps both in memory
-    const bool ok = (A_KCONTIG || !O3) ? (a_ok[it] && a_k[it] < kend) : ap < a_end;
+    const bool ok = ((A_KCONTIG || !O3) ? (a_ok[it] && a_k[it] < kend) : ap < a_end) && q_ablate != 2;
     const float* src = ok ? ap + 0 : q_zero + 0;
     if (GLDS_A) {
       if (tid + it * NT < BK * (ROWS / 4))
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
     // lane constants are slot-independent in the k-row-major layout (slot 0 holds them); s_* are wave-uniform
     constexpr int lc = KM ? 0 : it;
     const int ys = b_ys0[lc] + q_dir * s_a[it], xs = b_xs0[lc] + q_dir * s_b[it];
-    const bool ok = b_ok[lc] && s_k[it] < kend && (unsigned)ys < (unsigned)q_SH && (unsigned)xs < (unsigned)q_SW;
+    const bool ok = b_ok[lc] && s_k[it] < kend && (unsigned)ys < (unsigned)q_SH && (unsigned)xs < (unsigned)q_SW && q_ablate != 2;
     const unsigned off = (unsigned)((s_ch[it] * q_SH + ys) * q_SW + xs) * (unsigned)N + (unsigned)b_n[lc];
     const float* src = ok ? q_src + off : q_zero;
     if (GLDS_B) {
@@ -513,16 +517,19 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
   // Measured on conv4 (N=256): 126 TFLOP/s with the block fetch, 121 spread, 120 spread + sched_group_barrier
   // interleave — the two resident waves of a SIMD already cover each other's staging phase, so SPREAD stays off.
   constexpr bool SPREAD = false && GLDS_A && GLDS_B;
-  constexpr bool PRIO = true;
+  const int prio = p.prio;   // 0: no priority changes; 1: MFMA phase high; 2: staging phase high (see GGParams::prio)
   constexpr int NP = NA + NB, PPS = (NP + BK / 2 - 1) / (BK / 2);
   unsigned long long tr_begin = tr_begin_k, tr_loop = 0, tr_stage = 0, tr_mfma = 0, tr_sync = 0, tr_min_m = ~0ull, tr_max_m = 0, tr_min_t = ~0ull, tr_max_t = 0;
-  if constexpr (kTrace) tr_loop = trace_clock();
+#ifdef CONVNET_GG_TRACE
+  tr_loop = trace_clock();
+#endif
+  if (prio == 2) __builtin_amdgcn_s_setprio(2);
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
     const bool more = c + 1 < nchunks;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
     if constexpr (kTrace) tr0 = trace_clock();
-    if (!SPREAD && more) fetch(kbeg + (c + 1) * BK, buf ^ 1);
+    if (!SPREAD && more && !(p.ablate == 1 && c >= 2)) fetch(kbeg + (c + 1) * BK, buf ^ 1);
     if constexpr (kTrace) tr1 = trace_clock();
     const float* as = As + buf * A_STAGE;
     const float* bs = Bs + buf * B_STAGE + (KM ? wc * CW : wc * BK * CW) + NTC * li;
@@ -534,7 +541,8 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
 #pragma unroll
       for (int t = 0; t < MT; ++t) a[0][t] = ar[lh * ROWS + t * 32];
       b4[0] = *reinterpret_cast<const fvec*>(bs + lh * BROW);
-      if (PRIO) __builtin_amdgcn_s_setprio(2);   // MFMA phase outranks the co-resident wave's staging VALU at issue
+      if (prio == 1) __builtin_amdgcn_s_setprio(2);
+      else if (prio == 2) __builtin_amdgcn_s_setprio(0);
       static_for<0, BK / 2>([&](auto KK) __attribute__((always_inline)) {
         constexpr int kk = decltype(KK)::value;
         constexpr int cur = kk & 1, nxt = cur ^ 1;
@@ -567,7 +575,8 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
           }
         }
       });
-      if (PRIO) __builtin_amdgcn_s_setprio(0);
+      if (prio == 1) __builtin_amdgcn_s_setprio(0);
+      else if (prio == 2) __builtin_amdgcn_s_setprio(2);
     } else {
       const float* ar = as + (wr * MT * 32 + li) * APITCH + 4 * lh;
 #pragma unroll
@@ -596,6 +605,7 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
       tr_min_t = min(tr_min_t, tr3 - tr0); tr_max_t = max(tr_max_t, tr3 - tr0);
     }
   }
+  if (prio == 2) __builtin_amdgcn_s_setprio(0);
 #ifdef CONVNET_GG_TRACE
   const unsigned long long tr_loop_end = trace_clock();
   auto trace_out = [&](unsigned long long t_end) {
@@ -704,6 +714,7 @@ struct WGParams {
   int splits;
   int k_tiles, f_tiles;
   float scaleTargets, scaleOutput;
+  int prio;           // issue priority scheme (wg_prio_mode()): 0 none, 1 MFMA phase high, 2 staging phase high
 };
 
 constexpr int WG_NB = 32;          // images per stage
@@ -900,9 +911,13 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
   }
   __syncthreads();
   const int swz = VEC ? ((li >> 1) & 7) : 0;   // (row >> 1) & 7 of every fragment row this lane reads (tile bases are multiples of 16)
+  const int prio = p.prio;
   for (int c = cbeg; c < cend; ++c) {
     const int buf = (c - cbeg) & 1;
+    if (prio == 2) __builtin_amdgcn_s_setprio(2);
     if (c + 1 < cend) fetch(c + 1, buf ^ 1);
+    if (prio == 2) __builtin_amdgcn_s_setprio(0);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(2);
     const float* ar = As + buf * A_STAGE + (wm * MT * TS + li) * PITCH;
     const float* br = Bs + buf * B_STAGE + (wn * NTL * TS + li) * PITCH;
 #pragma unroll
@@ -925,6 +940,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
               acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t][e], b4[u][e], acc[t][u], 0, 0, 0);
           }
     }
+    if (prio == 1) __builtin_amdgcn_s_setprio(0);
     if (c + 1 < cend) stash(buf ^ 1);
     __syncthreads();
   }
@@ -1044,6 +1060,17 @@ const char* t_op = "";
 double t_flops = 0.0;
 double t_exec = 0.0;   // MFMA work the launch issues when it differs from the algorithmic t_flops (0 = same)
 
+// Issue-priority scheme of gg_kernel's main loop (CONVNET_GG_PRIO overrides, for A/B runs).
+inline int gg_prio_mode() {
+  static const int v = [] { const char* e = getenv("CONVNET_GG_PRIO"); return e && *e ? atoi(e) : 1; }();
+  return v;
+}
+
+inline int wg_prio_mode() {
+  static const int v = [] { const char* e = getenv("CONVNET_WG_PRIO"); return e && *e ? atoi(e) : 0; }();
+  return v;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename Kern>
@@ -1066,6 +1093,7 @@ void gg_launch_classes(GGParams& p, GGClassTable& ct, bool vec) {
   p.nblk = divup(p.N, CW);
   p.row_tiles = divup(p.R, ROWS);
   p.zero = zero_page();
+  p.prio = gg_prio_mode();
   p.splits = 1;
   p.chunks_per_split = 1 << 24;
   p.partial = nullptr;
@@ -1097,10 +1125,15 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   constexpr int B_STAGE = WC * BK * CW;
   p.nblk = divup(p.N, CW);
   p.ncols = p.G * p.nblk;
-  const size_t lds = sizeof(float) * 2 * (A_STAGE + B_STAGE);
+  // CONVNET_GG_LDS_PAD (diagnostic): extra dynamic LDS per block, e.g. 65536 to force ONE resident block per CU
+  static const size_t lds_pad = [] { const char* e = getenv("CONVNET_GG_LDS_PAD"); return e && *e ? (size_t)atol(e) : (size_t)0; }();
+  const size_t lds = sizeof(float) * 2 * (A_STAGE + B_STAGE) + lds_pad;
   p.row_tiles = divup(p.R, ROWS);
   p.col_tiles = divup(p.ncols, WC);
   p.zero = zero_page();
+  p.prio = gg_prio_mode();
+  static const int ablate = [] { const char* e = getenv("CONVNET_GG_ABLATE"); return e && *e ? atoi(e) : 0; }();
+  p.ablate = ablate;
   const int tiles = p.row_tiles * p.col_tiles;
   const int kchunks = divup(p.K, BK);
   // 3 blocks per CU (768 slots) for launches with at least two such rounds of tiles; only the 128-row r-contiguous
@@ -1234,6 +1267,7 @@ void wg_launch_cfg(WGParams& p, bool vec) {
   if (p.bias_dst && divup(p.K + 1, KT) != p.k_tiles) p.bias_dst = nullptr;   // no padding row to spare: caller sums separately
   p.f_tiles = divup(p.F, FT);
   p.zero = zero_page();
+  p.prio = wg_prio_mode();
   const int tiles = p.k_tiles * p.f_tiles;
   const size_t total = (size_t)(p.K + (p.bias_dst ? 1 : 0)) * p.F;
   // one full round of resident blocks (2 per CU): floor, not ceil — 568 blocks on 512 slots take two

@@ -73,35 +73,43 @@ int main(int argc, char** argv) {
     r.push_back({(unsigned)o[0], (unsigned)o[1] & 15, o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10], o[11], o[12], o[13]});
   }
   if (r.empty()) { printf("no trace records\n"); return 1; }
-  unsigned long long t0 = ~0ull, t1 = 0;
-  for (auto& q : r) { t0 = std::min(t0, q.b); t1 = std::max(t1, q.e); }
-  const double span = (double)(t1 - t0);
-  printf("%s %s: %zu traced blocks, event time %.1f us, first start -> last end %.0f ticks (%.1f ticks/us)\n", layer.c_str(), dir.c_str(), r.size(), ms * 1e3,
-         span, span / (ms * 1e3));
-  auto pct = [](std::vector<double> v, double p) { std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; };
-  std::vector<double> start, end, dur, pro, epi;
+  // s_memtime counters of different XCDs are not aligned: every time is taken relative to the first block start on its own XCD
+  std::map<unsigned, unsigned long long> x0, x1;
   for (auto& q : r) {
-    start.push_back((double)(q.b - t0)); end.push_back((double)(q.e - t0)); dur.push_back((double)(q.e - q.b));
-    pro.push_back((double)(q.lb - q.b)); epi.push_back((double)(q.e - q.le));
+    if (!x0.count(q.xcc) || q.b < x0[q.xcc]) x0[q.xcc] = q.b;
+    if (!x1.count(q.xcc) || q.e > x1[q.xcc]) x1[q.xcc] = q.e;
+  }
+  double span = 0;
+  for (auto& kv : x0) span = std::max(span, (double)(x1[kv.first] - kv.second));
+  printf("%s %s: %zu traced blocks, event time %.1f us, longest XCD span %.0f ticks (%.0f ticks/us)\n", layer.c_str(), dir.c_str(), r.size(), ms * 1e3, span,
+         span / (ms * 1e3));
+  auto pct = [](std::vector<double> v, double p) { std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; };
+  std::vector<double> start, end, dur, pro, epi, loop;
+  for (auto& q : r) {
+    start.push_back((double)(q.b - x0[q.xcc])); end.push_back((double)(q.e - x0[q.xcc])); dur.push_back((double)(q.e - q.b));
+    pro.push_back((double)(q.lb - q.b)); epi.push_back((double)(q.e - q.le)); loop.push_back((double)(q.le - q.lb) / (double)std::max(1ull, q.n));
   }
   printf("block start      p0 %.0f  p50 %.0f  p95 %.0f  max %.0f\n", pct(start, 0), pct(start, .5), pct(start, .95), pct(start, 1));
-  printf("block end        p0 %.0f  p5 %.0f  p50 %.0f  p95 %.0f  max %.0f   (resident share of the span: mean end-start %.3f)\n", pct(end, 0), pct(end, .05),
-         pct(end, .5), pct(end, .95), pct(end, 1), [&] { double s = 0; for (double d : dur) s += d; return s / dur.size() / span; }());
-  printf("prologue (start -> loop)   p50 %.0f  p95 %.0f ;  epilogue (loop end -> end)  p50 %.0f  p95 %.0f\n", pct(pro, .5), pct(pro, .95), pct(epi, .5), pct(epi, .95));
+  printf("block end        p0 %.0f  p5 %.0f  p50 %.0f  p95 %.0f  max %.0f   (mean block duration / span %.3f)\n", pct(end, 0), pct(end, .05), pct(end, .5),
+         pct(end, .95), pct(end, 1), [&] { double s = 0; for (double d : dur) s += d; return s / dur.size() / span; }());
+  printf("prologue p50 %.0f p95 %.0f ; epilogue p50 %.0f p95 %.0f ; loop ticks per chunk p5 %.0f p50 %.0f p95 %.0f\n", pct(pro, .5), pct(pro, .95), pct(epi, .5),
+         pct(epi, .95), pct(loop, .05), pct(loop, .5), pct(loop, .95));
   for (int slot = 0; slot < 2; ++slot) {
     double n = 0, st = 0, mf = 0, sy = 0, cnt = 0, minm = 0, maxm = 0, mint = 0, maxt = 0, d = 0;
     for (auto& q : r) {
       if ((int)(q.hw & 1) != slot) continue;
       cnt += 1; n += q.n; st += q.st; mf += q.mf; sy += q.sy; minm += q.minm; maxm += q.maxm; mint += q.mint; maxt += q.maxt; d += (double)(q.e - q.b);
+      st += 0;
     }
     if (cnt == 0) continue;
+    double lp = 0;
+    for (auto& q : r) if ((int)(q.hw & 1) == slot) lp += (double)(q.le - q.lb);
+    printf("wave slot %d: loop ticks per chunk %.0f\n", slot, lp / n);
     printf("wave slot %d: %4.0f blocks, %.1f chunks each; per chunk: staging %.0f  mfma-phase %.0f  wait+barrier %.0f  (total %.0f); per-block min/max mfma-phase %.0f / %.0f, "
            "min/max chunk %.0f / %.0f; block duration %.0f\n", slot, cnt, n / cnt, st / n, mf / n, sy / n, (st + mf + sy) / n, minm / cnt, maxm / cnt, mint / cnt, maxt / cnt, d / cnt);
   }
-  std::map<unsigned, std::pair<double, int>> xcc;
-  for (auto& q : r) { xcc[q.xcc].first += (double)(q.e - t0); xcc[q.xcc].second++; }
-  printf("mean block end per XCD:");
-  for (auto& kv : xcc) printf("  x%u %.0f (%d)", kv.first, kv.second.first / kv.second.second, kv.second.second);
+  printf("span per XCD:");
+  for (auto& kv : x0) printf("  x%u %.0f", kv.first, (double)(x1[kv.first] - kv.second));
   printf("\n");
   return 0;
 }
