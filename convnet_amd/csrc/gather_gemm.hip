@@ -61,7 +61,8 @@ struct GGParams {
   int R, K, N;
   int lda;            // A[r + lda*k] (r-contiguous) or A[k + lda*r] (k-contiguous)
   int GX, G;          // output pixel grid of this launch: G = GY*GX pixels, m = oy*GX + ox
-  int TX, TYX;        // taps: k = ch*TYX + a*TX + b
+  int TX, TYX;        // taps: k = ch*TYX + a*TX + b   (channel-major, KC == 0)
+  int KC;             // > 0: TAP-major reduction order k = (a*TX + b)*KC + ch over a filter bank re-laid to match (ggp_kernel)
   int SH, SW;         // source image
   int ssy, ssx, y0, x0, dir;       // source row of tap a: oy*ssy + y0 + dir*a
   int DW, DP;         // dest image width, pixels per channel (DH*DW)
@@ -197,6 +198,53 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT]
   }
 }
 
+// Which tile does this block compute, and with which per-class fields?  Shared by gg_kernel and ggp_kernel.
+struct GGTile {
+  const float* A;
+  int K, GX, G, TX, TYX, y0, x0, dy0, dx0, ncols, col_tiles;
+  int L, tsplit;   // logical tile; tsplit >= 0: one K-range of a tail tile
+};
+__device__ __forceinline__ bool gg_select_tile(const GGParams& p, const GGClassTable& ct, GGTile& t) {
+  t.A = p.A; t.K = p.K; t.GX = p.GX; t.G = p.G; t.TX = p.TX; t.TYX = p.TYX; t.y0 = p.y0; t.x0 = p.x0; t.dy0 = p.dy0; t.dx0 = p.dx0;
+  t.ncols = p.ncols; t.col_tiles = p.col_tiles; t.tsplit = -1;
+  if (ct.n > 0) {
+    const int b = blockIdx.x;
+    if (b >= ct.c[ct.n - 1].tile_end) return false;
+    int c = 0;
+    while (b >= ct.c[c].tile_end) ++c;
+    const int cbeg = c > 0 ? ct.c[c - 1].tile_end : 0;
+    {
+      // XCD-aware order inside the class (hardware places block b on XCD b%8): the blocks of this class that land on one XCD
+      // take a CONTIGUOUS run of its logical tiles, so neighbouring pixels — which gather overlapping taps — share one L2.
+      // Without it every XCD saw pixels 8 apart and conv2's dgrad fetched each deriv element once per tap (4.2 GiB for a
+      // 169 MiB tensor, profiles/r01_pmc_traffic_bench.json).  Exact counts, no padding blocks: residue r = i%8 owns
+      // q + (r < m) tiles starting at r*q + min(r, m).
+      const int i = b - cbeg, T = ct.c[c].tile_end - cbeg;
+      const int q = T >> 3, m = T & 7, r = i & 7;
+      t.L = r * q + (r < m ? r : m) + (i >> 3);
+    }
+    const GGClass& k = ct.c[c];
+    t.A = k.A; t.K = k.K; t.GX = k.GX; t.G = k.G; t.TX = k.TX; t.TYX = k.TYX;
+    t.y0 = k.y0; t.x0 = k.x0; t.dy0 = k.dy0; t.dx0 = k.dx0; t.ncols = k.ncols; t.col_tiles = k.col_tiles;
+  } else if (p.tail_splits > 1) {
+    const int k = blockIdx.x & 7, i = blockIdx.x >> 3;
+    if (i < p.tail_tf8) {
+      t.L = k * p.tail_tf8 + i;
+    } else {
+      const int j = k * p.tail_tt8 + (i - p.tail_tf8);
+      if (j >= (p.row_tiles * t.col_tiles - p.tail_first) * p.tail_splits) return false;
+      t.L = p.tail_first + j / p.tail_splits;
+      t.tsplit = j % p.tail_splits;
+    }
+  } else {
+    const int tiles = p.row_tiles * t.col_tiles;
+    const int per = (tiles + 7) >> 3;
+    t.L = xcd_remap(blockIdx.x, tiles);
+    if (t.L >= tiles || (int)blockIdx.x >= per * 8) return false;
+  }
+  return true;
+}
+
 // CW = images per wave-column (128: 4 interleaved 32-image MFMA column tiles per wave, ds_read_b128;
 // 64: 2 tiles, ds_read_b64 — used with MT=3 so a 96-row problem (conv1 fprop, conv2 dgrad) fills its tile).
 // O3 = the 3-blocks-per-CU build (launch bound 3 waves/SIMD + the k-row-major B stage that makes it fit): chosen by the
@@ -219,45 +267,11 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
 
   // fields a stride class overrides live in scalars; everything else is read from the kernarg struct in place
   const GGParams& p = pin;
-  const float* pA = p.A;
-  int pK = p.K, pGX = p.GX, pG = p.G, pTX = p.TX, pTYX = p.TYX, py0 = p.y0, px0 = p.x0, pdy0 = p.dy0, pdx0 = p.dx0, pncols = p.ncols,
-      pcol_tiles = p.col_tiles;
-  int L, tsplit = -1;   // tsplit >= 0: this block computes one K-range of a tail tile
-  if (ct.n > 0) {
-    const int b = blockIdx.x;
-    if (b >= ct.c[ct.n - 1].tile_end) return;
-    int c = 0;
-    while (b >= ct.c[c].tile_end) ++c;
-    const int cbeg = c > 0 ? ct.c[c - 1].tile_end : 0;
-    {
-      // XCD-aware order inside the class (hardware places block b on XCD b%8): the blocks of this class that land on one XCD
-      // take a CONTIGUOUS run of its logical tiles, so neighbouring pixels — which gather overlapping taps — share one L2.
-      // Without it every XCD saw pixels 8 apart and conv2's dgrad fetched each deriv element once per tap (4.2 GiB for a
-      // 169 MiB tensor, profiles/r01_pmc_traffic_bench.json).  Exact counts, no padding blocks: residue r = i%8 owns
-      // q + (r < m) tiles starting at r*q + min(r, m).
-      const int i = b - cbeg, T = ct.c[c].tile_end - cbeg;
-      const int q = T >> 3, m = T & 7, r = i & 7;
-      L = r * q + (r < m ? r : m) + (i >> 3);
-    }
-    const GGClass& k = ct.c[c];
-    pA = k.A; pK = k.K; pGX = k.GX; pG = k.G; pTX = k.TX; pTYX = k.TYX;
-    py0 = k.y0; px0 = k.x0; pdy0 = k.dy0; pdx0 = k.dx0; pncols = k.ncols; pcol_tiles = k.col_tiles;
-  } else if (p.tail_splits > 1) {
-    const int k = blockIdx.x & 7, i = blockIdx.x >> 3;
-    if (i < p.tail_tf8) {
-      L = k * p.tail_tf8 + i;
-    } else {
-      const int j = k * p.tail_tt8 + (i - p.tail_tf8);
-      if (j >= (p.row_tiles * pcol_tiles - p.tail_first) * p.tail_splits) return;
-      L = p.tail_first + j / p.tail_splits;
-      tsplit = j % p.tail_splits;
-    }
-  } else {
-    const int tiles = p.row_tiles * pcol_tiles;
-    const int per = (tiles + 7) >> 3;
-    L = xcd_remap(blockIdx.x, tiles);
-    if (L >= tiles || (int)blockIdx.x >= per * 8) return;
-  }
+  GGTile T;
+  if (!gg_select_tile(p, ct, T)) return;
+  const float* const pA = T.A;
+  const int pK = T.K, pGX = T.GX, pG = T.G, pTX = T.TX, pTYX = T.TYX, py0 = T.y0, px0 = T.x0, pdy0 = T.dy0, pdx0 = T.dx0, pncols = T.ncols;
+  const int L = T.L, tsplit = T.tsplit;   // tsplit >= 0: this block computes one K-range of a tail tile
   (void)pG;
   const int row_tile = L % p.row_tiles, col_tile = L / p.row_tiles;
   const int split = blockIdx.y;
@@ -639,6 +653,208 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
 #endif
 }
 
+// -------------------------------------------------------------------------------------------------
+// ggp_kernel: gg_kernel's r-contiguous direct-to-LDS build with a PRODUCER wave.
+//
+// Measured on gg_kernel (profiles/r02_gg_loop_diagnosis.md): with all staging removed the same main loop runs 11-14 % faster; about
+// half of that is the staging instructions themselves — ~130 VALU of address arithmetic and 6 LDS-DMA issues per wave per chunk,
+// which an in-order wave executes INSTEAD of feeding the matrix pipe — and half is waiting for the loads at the chunk-closing
+// vmcnt(0).  Here a fifth wave does all of it: it computes every address, issues all 24 `global_load_lds` of a chunk into a
+// THREE-stage LDS ring two chunks ahead, and arrives at the chunk barrier once the NEXT chunk has landed.  The four consumer
+// waves run nothing but fragment reads, MFMAs and that one barrier per chunk; they carry no staging state (≈150 VGPRs, so the
+// ten waves of the two resident blocks fit 3/3/2/2 on the four SIMDs).
+//
+// The B stage is k-row major ([krow][wave-column][image], 64 lanes x 16 B = exactly one k-row), so a producer instruction's
+// (channel, tap_y, tap_x) is wave-uniform and lives in SGPRs; a lane's (wave-column, image quad) never changes.  Same MFMA order,
+// same epilogue, same tile selection as gg_kernel: results are bit-identical to it.
+// -------------------------------------------------------------------------------------------------
+template <int WR, int WC, int MT, int CW>
+__global__ __launch_bounds__(WR* WC * 64 + 64, 3) void ggp_kernel(const GGParams pin, const GGClassTable ct) {
+  constexpr int NC = WR * WC * 64;   // consumer threads
+  constexpr int NTC = CW / 32, CW4 = CW / 4;
+  using fvec = __attribute__((ext_vector_type(NTC))) float;
+  constexpr int ROWS = WR * MT * 32;
+  constexpr int A_STAGE = BK * ROWS, B_STAGE = WC * BK * CW, ST = 3;
+  constexpr int NA = BK * (ROWS / 4) / 64, NB = WC * BK * CW4 / 64;   // producer wave-instructions per chunk
+  static_assert(WC * CW4 == 64, "one producer instruction = one k-row of the B stage");
+  static_assert((BK * (ROWS / 4)) % 64 == 0 && NB == BK, "whole wave-instructions");
+  constexpr int BROW = WC * CW;      // floats between consecutive k-rows of the B stage
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                  // [ST][A_STAGE]
+  float* Bs = smem + ST * A_STAGE;   // [ST][B_STAGE]
+
+  const GGParams& p = pin;
+  GGTile T;
+  if (!gg_select_tile(p, ct, T)) return;
+  const int L = T.L, tsplit = T.tsplit;
+  const int row_tile = L % p.row_tiles, col_tile = L / p.row_tiles;
+  const int split = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r0 = row_tile * ROWS;
+  const int N = p.N;
+
+  const int cps = tsplit >= 0 ? p.tail_cps : p.chunks_per_split;
+  const int kbeg = (tsplit >= 0 ? tsplit : split) * cps * BK;
+  int kend = kbeg + cps * BK;
+  if (kend > T.K) kend = T.K;
+  const int nchunks = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  // vmcnt(n) alone (expcnt / lgkmcnt untouched): low four bits in [3:0], high two in [15:14]
+  constexpr int kLoads = NA + NB;
+  static_assert(kLoads < 64, "vmcnt immediate");
+  constexpr int WAIT_ONE_CHUNK_IN_FLIGHT = (kLoads & 15) | ((kLoads >> 4) << 14) | 0x0F70;
+  constexpr int WAIT_ALL_LOADS = 0x0F70;
+
+  if (wave == WR * WC) {
+    // ================================ producer wave ================================
+    __builtin_amdgcn_s_setprio(3);
+    // lane constants of the B stage: this lane's (wave-column, image quad) and the source pixel of tap (0,0)
+    const int wcol = lane / CW4, c4 = lane % CW4;
+    const int colid = col_tile * WC + wcol;
+    const bool col_ok = colid < T.ncols;
+    const int m = col_ok ? colid / p.nblk : 0, blk = col_ok ? colid % p.nblk : 0;
+    const int oy = m / T.GX, ox = m - oy * T.GX;
+    const int ys0 = oy * p.ssy + T.y0, xs0 = ox * p.ssx + T.x0;
+    const int bn = blk * CW + 4 * c4;
+    const bool b_ok = col_ok && bn < N;
+    // TAP-major reduction order: k = tap*KC + ch, KC % BK == 0, so the BK k-rows of a chunk are BK consecutive channels of ONE
+    // tap: every lane's source pixel (and whether it exists) is fixed for the chunk and k-row `it` is a constant plane stride
+    // away — the producer spends two VALU per load instead of a (channel, tap_y, tap_x) decode with carries.
+    const int TX = T.TX, KC = p.KC;
+    int k0 = kbeg;
+    int tap = k0 / KC, ch0 = k0 - tap * KC;
+    int ta = tap / TX, tb = tap - ta * TX;
+    const float* const zero = p.zero;
+    const float* const src = p.src;
+    const int dir = p.dir, SH = p.SH, SW = p.SW, lda = p.lda, R = p.R;
+    const unsigned plane_bytes = (unsigned)SH * (unsigned)SW * (unsigned)N * 4u;   // < 2^31 floats per tensor (conv_geo)
+    const float* bptr;        // this lane's element of k-row 0 of the next chunk to issue
+    unsigned bstride;         // bytes between consecutive k-rows for this lane (0 on the zero page)
+    auto retap = [&]() __attribute__((always_inline)) {
+      const int ys = ys0 + dir * ta, xs = xs0 + dir * tb;
+      const bool ok = b_ok && (unsigned)ys < (unsigned)SH && (unsigned)xs < (unsigned)SW;
+      const unsigned off = (unsigned)((ch0 * SH + ys) * SW + xs) * (unsigned)N + (unsigned)bn;
+      bptr = ok ? src + off : zero;
+      bstride = ok ? plane_bytes : 0u;
+    };
+    retap();
+    // A stage: lane-linear [krow][ROWS]; instruction `it` covers 16-byte pieces 64*it .. 64*it+63 of the chunk
+    unsigned a_off[NA];   // byte offset of this lane's piece of instruction `it` from the chunk's first filter row
+    bool a_ok[NA];
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int idx = lane + 64 * it;
+      const int krow = idx / (ROWS / 4), q = idx - krow * (ROWS / 4);
+      a_ok[it] = r0 + 4 * q < R;
+      a_off[it] = (unsigned)(krow * lda + r0 + 4 * q) * 4u;
+    }
+    const char* abase = reinterpret_cast<const char*>(T.A) + (size_t)lda * k0 * 4;   // wave-uniform
+    const size_t a_chunk_bytes = (size_t)lda * BK * 4;
+
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+      for (int it = 0; it < NA; ++it) {
+        const float* ap = a_ok[it] ? reinterpret_cast<const float*>(abase + a_off[it]) : zero;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)ap, (lds_ptr_t)(As + stage * A_STAGE + 4 * 64 * it), 16, 0, 0);
+      }
+      const char* bp = reinterpret_cast<const char*>(bptr);
+#pragma unroll
+      for (int it = 0; it < NB; ++it) {
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)bp, (lds_ptr_t)(Bs + stage * B_STAGE + 4 * 64 * it), 16, 0, 0);
+        bp += bstride;
+      }
+      // next chunk: BK channels on, or the next tap
+      abase += a_chunk_bytes;
+      k0 += BK;
+      ch0 += BK;
+      if (ch0 >= KC) {
+        ch0 = 0;
+        if (++tb == TX) { tb = 0; ++ta; }
+        retap();
+      } else {
+        bptr = reinterpret_cast<const float*>(bp);
+      }
+    };
+
+    if (nchunks > 0) issue(0);
+    if (nchunks > 1) issue(1);
+    if (nchunks > 1) __builtin_amdgcn_s_waitcnt(WAIT_ONE_CHUNK_IN_FLIGHT); else __builtin_amdgcn_s_waitcnt(WAIT_ALL_LOADS);
+    __builtin_amdgcn_s_barrier();
+    int fill = 2;   // stage of chunk c + 2
+    for (int c = 0; c < nchunks; ++c) {
+      const bool more2 = c + 2 < nchunks;
+      if (more2 && p.ablate != 1) issue(fill);
+      fill = fill == ST - 1 ? 0 : fill + 1;
+      // chunk c+1 must have landed before the consumers are released into it
+      if (more2 && p.ablate != 1) __builtin_amdgcn_s_waitcnt(WAIT_ONE_CHUNK_IN_FLIGHT); else __builtin_amdgcn_s_waitcnt(WAIT_ALL_LOADS);
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  // ================================ consumer waves ================================
+  const int wr = wave / WC, wc = wave % WC;
+  const int li = lane & 31, lh = lane >> 5;
+  f32x16 acc[MT][NTC];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int u = 0; u < NTC; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+
+  __syncthreads();   // chunk 0 has landed (the fences of __syncthreads keep LDS reads on their side of the barrier)
+  // (Tried: closing barrier in front of the last k-step with the next chunk's first fragments requested right behind it — 123 vs
+  // 130 TFLOP/s on conv4; the compiler's own placement, barrier after the first MFMA of the last k-step, is the better one.)
+  int stage = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const float* ar = As + stage * A_STAGE + wr * MT * 32 + li;
+    const float* bs = Bs + stage * B_STAGE + wc * CW + NTC * li;
+    float a[2][MT];
+    fvec b4[2];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) a[0][t] = ar[lh * ROWS + t * 32];
+    b4[0] = *reinterpret_cast<const fvec*>(bs + lh * BROW);
+    static_for<0, BK / 2>([&](auto KK) __attribute__((always_inline)) {
+      constexpr int kk = decltype(KK)::value;
+      constexpr int cur = kk & 1, nxt = cur ^ 1;
+      if constexpr (kk + 1 < BK / 2) {
+        const int krow = 2 * (kk + 1) + lh;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a[nxt][t] = ar[krow * ROWS + t * 32];
+        b4[nxt] = *reinterpret_cast<const fvec*>(bs + krow * BROW);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < NTC; ++u)
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], b4[cur][u], acc[t][u], 0, 0, 0);
+    });
+    stage = stage == ST - 1 ? 0 : stage + 1;
+    __syncthreads();   // every consumer is done with this stage; the producer has the next chunk in LDS
+  }
+
+  // ---- epilogue: gg_kernel's ---------------------------------------------------------------------
+  if (tsplit >= 0) {
+    float* pp = p.tail_partial + ((size_t)(L - p.tail_first) * p.tail_splits + tsplit) * (size_t)(ROWS * WC * CW);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        fvec v;
+#pragma unroll
+        for (int u = 0; u < NTC; ++u) v[u] = acc[t][u][reg];
+        *reinterpret_cast<fvec*>(pp + ((size_t)(t * 16 + reg) * NC + tid) * NTC) = v;
+      }
+    return;
+  }
+  gg_epilogue<WR, WC, MT, CW, true>(p, acc, row_tile, col_tile, split, T.ncols, T.GX, T.dy0, T.dx0);
+}
+
 // Sums the tail_splits partial tiles of one tail tile in fixed order and applies the normal epilogue.
 template <int WR, int WC, int MT, int CW, bool VEC>
 __global__ __launch_bounds__(WR* WC * 64) void gg_tail_fix_kernel(const GGParams p) {
@@ -678,17 +894,38 @@ __global__ void gg_reduce_kernel(float* __restrict__ dst, const float* __restric
 
 // Re-lay the filter bank for one stride class of the input-gradient gather:
 // Wt[c + C*(b + TXc*(a + TYc*f))] = W[f + F*((cx + s_x*b) + Kx*((cy + s_y*a) + Ky*c))].
+// tap_major: Wt[c + C*(f + F*(b + TXc*a))] — the reduction index runs k = tap*F + f (ggp_kernel's order) instead of f*TYXc + tap.
 __global__ void dgrad_filter_kernel(const float* __restrict__ W, float* __restrict__ Wt, int F, int C, int Ky, int Kx, int cy,
-                                    int cx, int sy, int sx, int TYc, int TXc) {
+                                    int cx, int sy, int sx, int TYc, int TXc, int tap_major) {
   const size_t total = (size_t)C * TXc * TYc * F;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = i % C;
     size_t r = i / C;
-    const int b = r % TXc;
-    r /= TXc;
-    const int a = r % TYc;
-    const int f = r / TYc;
+    int a, b, f;
+    if (tap_major) {
+      f = r % F;
+      r /= F;
+      b = r % TXc;
+      a = r / TXc;
+    } else {
+      b = r % TXc;
+      r /= TXc;
+      a = r % TYc;
+      f = r / TYc;
+    }
     Wt[i] = W[(size_t)f + (size_t)F * ((cx + sx * b) + Kx * ((cy + sy * a) + Ky * c))];
+  }
+}
+
+// Forward filters in TAP-major reduction order for ggp_kernel: Wt[f + F*(c + C*tap)] = W[f + F*(tap + TYX*c)]  (tap = ky*Kx + kx).
+__global__ void filter_tapmajor_kernel(const float* __restrict__ W, float* __restrict__ Wt, int F, int C, int TYX) {
+  const size_t total = (size_t)F * C * TYX;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int f = i % F;
+    size_t r = i / F;
+    const int c = r % C;
+    const int tap = r / C;
+    Wt[i] = W[(size_t)f + (size_t)F * (tap + (size_t)TYX * c)];
   }
 }
 
@@ -1066,6 +1303,25 @@ inline int gg_prio_mode() {
   return v;
 }
 
+// The producer-wave build of the gather-GEMM (ggp_kernel) for the launches that have one (r-contiguous A, vector path,
+// 64 pieces per k-row).  CONVNET_GG_PRODUCER=0/1 overrides for A/B runs.
+inline bool gg_producer_mode() {
+  static const bool v = [] { const char* e = getenv("CONVNET_GG_PRODUCER"); return e && *e ? atoi(e) != 0 : false; }();
+  return v;
+}
+
+// ggp_kernel exists for the tile shapes whose B stage has 64 sixteen-byte pieces per k-row (gg_run picks those for R > 32).
+inline bool ggp_shape_ok(int R, int KC) { return gg_producer_mode() && R > 32 && KC > 0 && KC % BK == 0 && getenv("CONVNET_GG_ROWS64") == nullptr; }
+
+template <typename Kern>
+int resident_slots(Kern kern, int threads, size_t lds) {
+  int n = 0;
+  CHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), threads, lds));
+  if (n < 1) n = 1;
+  if (getenv("CONVNET_GG_VERBOSE")) fprintf(stderr, "libconvnet_hip: %d resident blocks per CU (%d threads, %zu B LDS)\n", n, threads, lds);
+  return n * 256;   // 256 CUs
+}
+
 inline int wg_prio_mode() {
   static const int v = [] { const char* e = getenv("CONVNET_WG_PRIO"); return e && *e ? atoi(e) : 0; }();
   return v;
@@ -1106,10 +1362,19 @@ void gg_launch_classes(GGParams& p, GGClassTable& ct, bool vec) {
     end += p.row_tiles * ct.c[i].col_tiles;
     ct.c[i].tile_end = end;
   }
-  static const std::string kname = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ",rc>";
+  static const std::string kname_g = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ",rc>";
+  static const std::string kname_p = "ggp_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ">";
+  const std::string& kname = p.KC > 0 ? kname_p : kname_g;
   KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, t_exec);
   dim3 grid(end), block(WR * WC * 64);
-  if (vec) {
+  if (p.KC > 0) {
+    CHIP_REQUIRE(vec && WC * (CW / 4) == 64);
+    if constexpr (WC * (CW / 4) == 64) {
+      const size_t lds3 = lds / 2 * 3;
+      allow_big_lds(ggp_kernel<WR, WC, MT, CW>, lds3);
+      hipLaunchKernelGGL((ggp_kernel<WR, WC, MT, CW>), grid, dim3(WR * WC * 64 + 64), lds3, stream(), p, ct);
+    }
+  } else if (vec) {
     allow_big_lds(gg_kernel<WR, WC, MT, CW, false, true>, lds);
     hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, false, true>), grid, block, lds, stream(), p, ct);
   } else {
@@ -1139,8 +1404,14 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   // 3 blocks per CU (768 slots) for launches with at least two such rounds of tiles; only the 128-row r-contiguous
   // vector build has the variant (it is the one whose register count sits between the 2- and 3-block limits).
   static const bool no_o3 = getenv("CONVNET_GG_NO_O3") != nullptr;
-  const bool o3 = !no_o3 && vec && !AK && WR == 2 && WC == 2 && MT == 2 && CW == 128 && tiles >= 2 * 768;
-  const int slots_launch = o3 ? 768 : kTargetBlocks;
+  const bool o3 = !no_o3 && vec && !AK && WR == 2 && WC == 2 && MT == 2 && CW == 128 && tiles >= 2 * 768 && p.KC == 0;
+  int slots_launch = o3 ? 768 : kTargetBlocks;
+  if constexpr (!AK && WC * (CW / 4) == 64) {
+    if (p.KC > 0) {
+      static const int pslots = resident_slots(ggp_kernel<WR, WC, MT, CW>, WR * WC * 64 + 64, sizeof(float) * 3 * (A_STAGE + B_STAGE));
+      slots_launch = pslots;
+    }
+  }
   // Split-K factor by wave quantisation: every block of a launch takes the same time, so a grid of b
   // blocks on `slots` resident-block slots runs ceil(b/slots) rounds and wastes the empty part of the
   // last one (338 tiles on 512 slots = 66 % busy; 3 K-splits = 1014 blocks = 99 %).  Pick the split with
@@ -1196,7 +1467,9 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   }
   dim3 grid(p.tail_splits > 1 ? 8 * (p.tail_tf8 + p.tail_tt8) : ((tiles + 7) / 8) * 8, splits);
   dim3 block(WR * WC * 64);
-  static const std::string kname = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + "," + (AK ? "kc" : "rc") + ">";
+  static const std::string kname_g = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + "," + (AK ? "kc" : "rc") + ">";
+  static const std::string kname_p = "ggp_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ">";
+  const std::string& kname = p.KC > 0 ? kname_p : kname_g;
   {
     KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, t_exec);
     if constexpr (!AK && WR == 2 && WC == 2 && MT == 2 && CW == 128) {
@@ -1205,7 +1478,17 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
         hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, true, true>), grid, block, lds, stream(), p, kNoClasses);
       }
     }
-    if (o3) {
+    bool donep = false;
+    if (p.KC > 0) CHIP_REQUIRE(!AK && vec && WC * (CW / 4) == 64);
+    if constexpr (!AK && WC * (CW / 4) == 64) {
+      if (p.KC > 0) {
+        const size_t lds3 = sizeof(float) * 3 * (A_STAGE + B_STAGE) + lds_pad;
+        allow_big_lds(ggp_kernel<WR, WC, MT, CW>, lds3);
+        hipLaunchKernelGGL((ggp_kernel<WR, WC, MT, CW>), grid, dim3(WR * WC * 64 + 64), lds3, stream(), p, kNoClasses);
+        donep = true;
+      }
+    }
+    if (o3 || donep) {
     } else if (vec) {
       allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, true>, lds);
       hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, true>), grid, block, lds, stream(), p, kNoClasses);
@@ -1377,6 +1660,19 @@ void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* tar
   p.nblk = divup(g.N, 128); p.ncols = p.G * p.nblk;
   p.scaleTargets = scaleTargets; p.relu = relu;
   const bool vec = g.N % 4 == 0 && g.F % 4 == 0 && aligned16(p.A) && aligned16(p.src) && aligned16(p.dst);
+  if (vec && ggp_shape_ok(g.F, g.C)) {
+    // producer-wave kernel: the reduction runs tap-major over a re-laid copy of the filter bank (a few MB, ~5 us)
+    if (p.TYX > 1) {
+      const size_t welems = (size_t)g.F * p.K;
+      float* wt = static_cast<float*>(workspace_aux(sizeof(float) * welems));
+      int nb = (int)((welems + 255) / 256);
+      if (nb > 2048) nb = 2048;
+      KernelTimer timer("filter_tapmajor_kernel", "conv_fprop", 0.0, 8.0 * welems);
+      hipLaunchKernelGGL(filter_tapmajor_kernel, dim3(nb), dim3(256), 0, stream(), filters->data_device, wt, g.F, g.C, p.TYX);
+      p.A = wt;
+    }
+    p.KC = g.C;
+  }
   t_op = "conv_fprop";
   t_flops = 2.0 * g.N * p.G * (double)g.F * p.K;
   t_exec = 0.0;
@@ -1432,6 +1728,8 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
   base.mask = mask ? mask->data_device : nullptr; base.post_scale = post_scale;
   const bool vec = g.N % 4 == 0 && g.C % 4 == 0 && aligned16(base.src) && aligned16(base.dst) && aligned16(base.mask);
   GGClassTable ct{};
+  const bool tapm = vec && ggp_shape_ok(g.C, g.F);   // producer-wave kernel: k = tap*F + f over tap-major class filters
+  if (tapm) base.KC = g.F;
   const bool multi = g.sy * g.sx > 1 && g.sy * g.sx <= kMaxClasses;   // all classes in one launch (no wave-quantisation per class)
   t_op = "conv_dgrad";
   // Work accounting.  ALGORITHMIC = the transposed convolution's MACs, 2*N*My*Mx*F*C*Ky*Kx (every output pixel meets every tap
@@ -1470,7 +1768,7 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
         if (nb > 2048) nb = 2048;
         KernelTimer timer("dgrad_filter_kernel", "conv_dgrad", 0.0, 8.0 * welems);
         hipLaunchKernelGGL(dgrad_filter_kernel, dim3(nb), dim3(256), 0, stream(), filters->data_device, wc, g.F, g.C, g.Ky,
-                           g.Kx, cy, cx, g.sy, g.sx, TYc, TXc);
+                           g.Kx, cy, cx, g.sy, g.sx, TYc, TXc, tapm ? 1 : 0);
       }
       GGClass k{};
       k.A = wc; k.K = g.F * TYc * TXc;
@@ -1604,7 +1902,9 @@ static int dot_impl(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target
     t_flops = 2.0 * m * (double)n * K;
     t_exec = 0.0;
     if (t2) {   // NT: A[r=f + F*k=d]
-      gg_run<false>(p, base_vec && n % 4 == 0, (size_t)m * n);
+      const bool v = base_vec && n % 4 == 0;
+      if (v && ggp_shape_ok(n, K)) p.KC = K;   // one tap: tap-major IS channel-major, no re-layout
+      gg_run<false>(p, v, (size_t)m * n);
     } else {    // NN: A[k=f + F*r=d]
       gg_run<true>(p, base_vec && K % 4 == 0 && mat2->size[0] % 4 == 0, (size_t)m * n);
     }
