@@ -84,7 +84,6 @@ struct GGParams {
   int tail_first, tail_splits, tail_cps, tail_tf8, tail_tt8;
   float* tail_partial;
   int prio;            // issue priority scheme of the main loop (gg_prio_mode())
-  int ablate;          // DIAGNOSTIC (CONVNET_GG_ABLATE, wrong results): 1 = no staging after the second chunk; 2 = every staging load reads the zero page
 };
 
 // A strided dgrad is one gather-GEMM per stride class (conv_down_impl); the classes differ only in the fields
@@ -384,12 +383,12 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
   // scalars for the staging lambdas (they capture these, not the parameter struct)
   const float* const q_zero = p.zero;
   const float* const q_src = p.src;
-  const int q_lda = p.lda, q_dir = p.dir, q_SH = p.SH, q_SW = p.SW, q_ablate = p.ablate;
+  const int q_lda = p.lda, q_dir = p.dir, q_SH = p.SH, q_SW = p.SW;
   const float* const a_end = pA + (size_t)p.lda * kend;   // r-contiguous A: first address of row k = kend
   auto fetch_a_piece = [&](auto IT, int buf) __attribute__((always_inline)) {
     constexpr int it = decltype(IT)::value;
     const float* const ap = a_ptr[it];   // rvalues: a conditional on two lvalues selects an ADDRESS and keeps both in memory
-    const bool ok = ((A_KCONTIG || !O3) ? (a_ok[it] && a_k[it] < kend) : ap < a_end) && q_ablate != 2;
+    const bool ok = ((A_KCONTIG || !O3) ? (a_ok[it] && a_k[it] < kend) : ap < a_end);
     const float* src = ok ? ap + 0 : q_zero + 0;
     if (GLDS_A) {
       if (tid + it * NT < BK * (ROWS / 4))
@@ -405,7 +404,7 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
     // lane constants are slot-independent in the k-row-major layout (slot 0 holds them); s_* are wave-uniform
     constexpr int lc = KM ? 0 : it;
     const int ys = b_ys0[lc] + q_dir * s_a[it], xs = b_xs0[lc] + q_dir * s_b[it];
-    const bool ok = b_ok[lc] && s_k[it] < kend && (unsigned)ys < (unsigned)q_SH && (unsigned)xs < (unsigned)q_SW && q_ablate != 2;
+    const bool ok = b_ok[lc] && s_k[it] < kend && (unsigned)ys < (unsigned)q_SH && (unsigned)xs < (unsigned)q_SW;
     const unsigned off = (unsigned)((s_ch[it] * q_SH + ys) * q_SW + xs) * (unsigned)N + (unsigned)b_n[lc];
     const float* src = ok ? q_src + off : q_zero;
     if (GLDS_B) {
@@ -543,7 +542,7 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
     const bool more = c + 1 < nchunks;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
     if constexpr (kTrace) tr0 = trace_clock();
-    if (!SPREAD && more && !(p.ablate == 1 && c >= 2)) fetch(kbeg + (c + 1) * BK, buf ^ 1);
+    if (!SPREAD && more) fetch(kbeg + (c + 1) * BK, buf ^ 1);
     if constexpr (kTrace) tr1 = trace_clock();
     const float* as = As + buf * A_STAGE;
     const float* bs = Bs + buf * B_STAGE + (KM ? wc * CW : wc * BK * CW) + NTC * li;
@@ -698,7 +697,31 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 3) void ggp_kernel(const GGParams
   const int kbeg = (tsplit >= 0 ? tsplit : split) * cps * BK;
   int kend = kbeg + cps * BK;
   if (kend > T.K) kend = T.K;
-  const int nchunks = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  int nchunks = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+
+  // Border-tap skipping.  In tap-major order a whole run of KC/BK chunks belongs to one tap; when every wave-column of the tile
+  // is an image block of ONE output pixel (N >= WC*CW images per pixel) and this block owns the whole reduction, the taps whose
+  // source pixel lies outside the image contribute exact zeros and are left out — producer and consumers walk the rectangle
+  // [a_lo, a_hi] x [b_lo, b_hi] of taps that exist.  (A dgrad gather otherwise issues 1.13x (conv2) to 1.40x (conv5) the algorithmic
+  // MACs on the zero page, a padded 3x3 fprop 1.11x.)  It pays on launches of several rounds; a single round ends with its
+  // slowest tile.
+  const int TYn = T.TYX / T.TX;
+  int a_lo = 0, a_hi = TYn - 1, b_lo = 0, b_hi = T.TX - 1;
+  const bool skip = tsplit < 0 && p.splits == 1 && p.nblk % WC == 0;
+  if (skip) {
+    const int m = (col_tile * WC) / p.nblk;
+    const int oy = m / T.GX, ox = m - oy * T.GX;
+    const int ys0 = oy * p.ssy + T.y0, xs0 = ox * p.ssx + T.x0;
+    if (p.dir > 0) {
+      a_lo = max(0, -ys0); a_hi = min(TYn - 1, p.SH - 1 - ys0);
+      b_lo = max(0, -xs0); b_hi = min(T.TX - 1, p.SW - 1 - xs0);
+    } else {
+      a_lo = max(0, ys0 - (p.SH - 1)); a_hi = min(TYn - 1, ys0);
+      b_lo = max(0, xs0 - (p.SW - 1)); b_hi = min(T.TX - 1, xs0);
+    }
+    const int na = a_hi - a_lo + 1, nb2 = b_hi - b_lo + 1;
+    nchunks = (na > 0 && nb2 > 0) ? na * nb2 * (p.KC / BK) : 0;
+  }
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -724,9 +747,13 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 3) void ggp_kernel(const GGParams
     // tap: every lane's source pixel (and whether it exists) is fixed for the chunk and k-row `it` is a constant plane stride
     // away — the producer spends two VALU per load instead of a (channel, tap_y, tap_x) decode with carries.
     const int TX = T.TX, KC = p.KC;
-    int k0 = kbeg;
-    int tap = k0 / KC, ch0 = k0 - tap * KC;
-    int ta = tap / TX, tb = tap - ta * TX;
+    int ch0 = 0, ta = a_lo, tb = b_lo;
+    if (!skip) {   // a K-range of a split starts inside the tap sequence
+      const int tap = kbeg / KC;
+      ch0 = kbeg - tap * KC;
+      ta = tap / TX;
+      tb = tap - ta * TX;
+    }
     const float* const zero = p.zero;
     const float* const src = p.src;
     const int dir = p.dir, SH = p.SH, SW = p.SW, lda = p.lda, R = p.R;
@@ -751,7 +778,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 3) void ggp_kernel(const GGParams
       a_ok[it] = r0 + 4 * q < R;
       a_off[it] = (unsigned)(krow * lda + r0 + 4 * q) * 4u;
     }
-    const char* abase = reinterpret_cast<const char*>(T.A) + (size_t)lda * k0 * 4;   // wave-uniform
+    const char* abase = reinterpret_cast<const char*>(T.A) + (size_t)lda * ((ta * TX + tb) * KC + ch0) * 4;   // wave-uniform
     const size_t a_chunk_bytes = (size_t)lda * BK * 4;
 
     auto issue = [&](int stage) __attribute__((always_inline)) {
@@ -766,15 +793,15 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 3) void ggp_kernel(const GGParams
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)bp, (lds_ptr_t)(Bs + stage * B_STAGE + 4 * 64 * it), 16, 0, 0);
         bp += bstride;
       }
-      // next chunk: BK channels on, or the next tap
-      abase += a_chunk_bytes;
-      k0 += BK;
+      // next chunk: BK channels on, or the next tap of the rectangle
       ch0 += BK;
       if (ch0 >= KC) {
         ch0 = 0;
-        if (++tb == TX) { tb = 0; ++ta; }
+        if (++tb > b_hi) { tb = b_lo; ++ta; }
+        abase = reinterpret_cast<const char*>(T.A) + (size_t)lda * ((ta * TX + tb) * KC) * 4;
         retap();
       } else {
+        abase += a_chunk_bytes;
         bptr = reinterpret_cast<const float*>(bp);
       }
     };
@@ -786,10 +813,10 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 3) void ggp_kernel(const GGParams
     int fill = 2;   // stage of chunk c + 2
     for (int c = 0; c < nchunks; ++c) {
       const bool more2 = c + 2 < nchunks;
-      if (more2 && p.ablate != 1) issue(fill);
+      if (more2) issue(fill);
       fill = fill == ST - 1 ? 0 : fill + 1;
       // chunk c+1 must have landed before the consumers are released into it
-      if (more2 && p.ablate != 1) __builtin_amdgcn_s_waitcnt(WAIT_ONE_CHUNK_IN_FLIGHT); else __builtin_amdgcn_s_waitcnt(WAIT_ALL_LOADS);
+      if (more2) __builtin_amdgcn_s_waitcnt(WAIT_ONE_CHUNK_IN_FLIGHT); else __builtin_amdgcn_s_waitcnt(WAIT_ALL_LOADS);
       __builtin_amdgcn_s_barrier();
     }
     return;
@@ -1297,16 +1324,18 @@ const char* t_op = "";
 double t_flops = 0.0;
 double t_exec = 0.0;   // MFMA work the launch issues when it differs from the algorithmic t_flops (0 = same)
 
-// Issue-priority scheme of gg_kernel's main loop (CONVNET_GG_PRIO overrides, for A/B runs).
+// Issue-priority scheme of gg_kernel's main loop (CONVNET_GG_PRIO overrides, for A/B runs).  Measured per layer (AlexNet, N=256):
+// raising the STAGING phase (2) beats raising the MFMA phase (1, round 1's choice) and no priority (0) by ~1 % — the co-resident
+// wave's address arithmetic and LDS-DMA issue finish sooner and its MFMA phase starts earlier.
 inline int gg_prio_mode() {
-  static const int v = [] { const char* e = getenv("CONVNET_GG_PRIO"); return e && *e ? atoi(e) : 1; }();
+  static const int v = [] { const char* e = getenv("CONVNET_GG_PRIO"); return e && *e ? atoi(e) : 2; }();
   return v;
 }
 
 // The producer-wave build of the gather-GEMM (ggp_kernel) for the launches that have one (r-contiguous A, vector path,
-// 64 pieces per k-row).  CONVNET_GG_PRODUCER=0/1 overrides for A/B runs.
+// 64 pieces per k-row).  On by default; CONVNET_GG_PRODUCER=0 restores gg_kernel everywhere (A/B runs).
 inline bool gg_producer_mode() {
-  static const bool v = [] { const char* e = getenv("CONVNET_GG_PRODUCER"); return e && *e ? atoi(e) != 0 : false; }();
+  static const bool v = [] { const char* e = getenv("CONVNET_GG_PRODUCER"); return e && *e ? atoi(e) != 0 : true; }();
   return v;
 }
 
@@ -1323,7 +1352,7 @@ int resident_slots(Kern kern, int threads, size_t lds) {
 }
 
 inline int wg_prio_mode() {
-  static const int v = [] { const char* e = getenv("CONVNET_WG_PRIO"); return e && *e ? atoi(e) : 0; }();
+  static const int v = [] { const char* e = getenv("CONVNET_WG_PRIO"); return e && *e ? atoi(e) : 2; }();
   return v;
 }
 
@@ -1365,7 +1394,7 @@ void gg_launch_classes(GGParams& p, GGClassTable& ct, bool vec) {
   static const std::string kname_g = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ",rc>";
   static const std::string kname_p = "ggp_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ">";
   const std::string& kname = p.KC > 0 ? kname_p : kname_g;
-  KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, t_exec);
+  KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, (p.KC > 0 && p.nblk % WC == 0) ? 0.0 : t_exec);
   dim3 grid(end), block(WR * WC * 64);
   if (p.KC > 0) {
     CHIP_REQUIRE(vec && WC * (CW / 4) == 64);
@@ -1397,8 +1426,6 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   p.col_tiles = divup(p.ncols, WC);
   p.zero = zero_page();
   p.prio = gg_prio_mode();
-  static const int ablate = [] { const char* e = getenv("CONVNET_GG_ABLATE"); return e && *e ? atoi(e) : 0; }();
-  p.ablate = ablate;
   const int tiles = p.row_tiles * p.col_tiles;
   const int kchunks = divup(p.K, BK);
   // 3 blocks per CU (768 slots) for launches with at least two such rounds of tiles; only the 128-row r-contiguous
@@ -1471,7 +1498,9 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   static const std::string kname_p = "ggp_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ">";
   const std::string& kname = p.KC > 0 ? kname_p : kname_g;
   {
-    KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, t_exec);
+    // ggp_kernel leaves out border taps when a tile is one pixel and owns its whole reduction: executed <= algorithmic then
+    const bool skips = p.KC > 0 && splits == 1 && p.nblk % WC == 0;
+    KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, skips ? 0.0 : t_exec);
     if constexpr (!AK && WR == 2 && WC == 2 && MT == 2 && CW == 128) {
       if (o3) {
         allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, true, true>, lds);
