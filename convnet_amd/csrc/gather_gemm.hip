@@ -62,7 +62,8 @@ struct GGParams {
   int lda;            // A[r + lda*k] (r-contiguous) or A[k + lda*r] (k-contiguous)
   int GX, G;          // output pixel grid of this launch: G = GY*GX pixels, m = oy*GX + ox
   int TX, TYX;        // taps: k = ch*TYX + a*TX + b   (channel-major, KC == 0)
-  int KC;             // > 0: TAP-major reduction order k = (a*TX + b)*KC + ch over a filter bank re-laid to match (ggp_kernel)
+  int KC;             // > 0 (ggp_kernel): reduction order k = ((cb*TYX + tap)*BK + c16, channel ch = cb*BK + c16 of KC — every chunk of BK
+                      // k-rows is ONE tap of one 16-channel block, taps innermost — over a filter bank re-laid to match
   int SH, SW;         // source image
   int ssy, ssx, y0, x0, dir;       // source row of tap a: oy*ssy + y0 + dir*a
   int DW, DP;         // dest image width, pixels per channel (DH*DW)
@@ -743,14 +744,16 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 3) void ggp_kernel(const GGParams
     const int ys0 = oy * p.ssy + T.y0, xs0 = ox * p.ssx + T.x0;
     const int bn = blk * CW + 4 * c4;
     const bool b_ok = col_ok && bn < N;
-    // TAP-major reduction order: k = tap*KC + ch, KC % BK == 0, so the BK k-rows of a chunk are BK consecutive channels of ONE
-    // tap: every lane's source pixel (and whether it exists) is fixed for the chunk and k-row `it` is a constant plane stride
-    // away — the producer spends two VALU per load instead of a (channel, tap_y, tap_x) decode with carries.
-    const int TX = T.TX, KC = p.KC;
-    int ch0 = 0, ta = a_lo, tb = b_lo;
-    if (!skip) {   // a K-range of a split starts inside the tap sequence
-      const int tap = kbeg / KC;
-      ch0 = kbeg - tap * KC;
+    // Reduction order k = (cb*TYX + tap)*BK + c16 (KC % BK == 0): the BK k-rows of a chunk are BK consecutive channels of ONE tap, so
+    // every lane's source pixel (and whether it exists) is fixed for the chunk and k-row `it` is a constant plane stride away — the
+    // producer spends one 64-bit add per load instead of a (channel, tap_y, tap_x) decode with carries.
+    const int TX = T.TX, KC = p.KC, TYX = T.TYX;
+    int cb = 0, ta = a_lo, tb = b_lo;   // 16-channel block, tap
+    (void)KC;
+    if (!skip) {   // a K-range of a split starts inside the chunk sequence (chunk index = cb*TYX + tap)
+      const int ci = kbeg / BK;
+      cb = ci / TYX;
+      const int tap = ci - cb * TYX;
       ta = tap / TX;
       tb = tap - ta * TX;
     }
@@ -763,7 +766,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 3) void ggp_kernel(const GGParams
     auto retap = [&]() __attribute__((always_inline)) {
       const int ys = ys0 + dir * ta, xs = xs0 + dir * tb;
       const bool ok = b_ok && (unsigned)ys < (unsigned)SH && (unsigned)xs < (unsigned)SW;
-      const unsigned off = (unsigned)((ch0 * SH + ys) * SW + xs) * (unsigned)N + (unsigned)bn;
+      const unsigned off = (unsigned)((cb * BK * SH + ys) * SW + xs) * (unsigned)N + (unsigned)bn;
       bptr = ok ? src + off : zero;
       bstride = ok ? plane_bytes : 0u;
     };
@@ -778,10 +781,11 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 3) void ggp_kernel(const GGParams
       a_ok[it] = r0 + 4 * q < R;
       a_off[it] = (unsigned)(krow * lda + r0 + 4 * q) * 4u;
     }
-    const char* abase = reinterpret_cast<const char*>(T.A) + (size_t)lda * ((ta * TX + tb) * KC + ch0) * 4;   // wave-uniform
-    const size_t a_chunk_bytes = (size_t)lda * BK * 4;
+    const char* const abase0 = reinterpret_cast<const char*>(T.A);
+    const size_t a_chunk_bytes = (size_t)lda * BK * 4;   // one chunk of filter rows; chunk index = cb*TYX + tap
 
     auto issue = [&](int stage) __attribute__((always_inline)) {
+      const char* const abase = abase0 + a_chunk_bytes * (size_t)(cb * TYX + ta * TX + tb);   // wave-uniform
 #pragma unroll
       for (int it = 0; it < NA; ++it) {
         const float* ap = a_ok[it] ? reinterpret_cast<const float*>(abase + a_off[it]) : zero;
@@ -793,17 +797,18 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 3) void ggp_kernel(const GGParams
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)bp, (lds_ptr_t)(Bs + stage * B_STAGE + 4 * 64 * it), 16, 0, 0);
         bp += bstride;
       }
-      // next chunk: BK channels on, or the next tap of the rectangle
-      ch0 += BK;
-      if (ch0 >= KC) {
-        ch0 = 0;
-        if (++tb > b_hi) { tb = b_lo; ++ta; }
-        abase = reinterpret_cast<const char*>(T.A) + (size_t)lda * ((ta * TX + tb) * KC) * 4;
-        retap();
-      } else {
-        abase += a_chunk_bytes;
-        bptr = reinterpret_cast<const float*>(bp);
+      // next chunk: the next tap of the rectangle for the same 16 channels, then the next channel block.  Taps innermost keeps
+      // what neighbouring tiles fetch for tap t+1 one chunk — not one whole tap run — away from what they fetched for tap t.
+      // (A/B, same box: channel blocks innermost — a whole run of KC/16 chunks per tap — is 5 % slower on conv2-5 and fetches
+      // 1.5x more through the fabric: what a neighbouring tile read for tap t is 16 MB of traffic away when this tile needs it for t+1)
+      if (++tb > b_hi) {
+        tb = b_lo;
+        if (++ta > a_hi) {
+          ta = a_lo;
+          ++cb;
+        }
       }
+      retap();
     };
 
     if (nchunks > 0) issue(0);
@@ -921,7 +926,8 @@ __global__ void gg_reduce_kernel(float* __restrict__ dst, const float* __restric
 
 // Re-lay the filter bank for one stride class of the input-gradient gather:
 // Wt[c + C*(b + TXc*(a + TYc*f))] = W[f + F*((cx + s_x*b) + Kx*((cy + s_y*a) + Ky*c))].
-// tap_major: Wt[c + C*(f + F*(b + TXc*a))] — the reduction index runs k = tap*F + f (ggp_kernel's order) instead of f*TYXc + tap.
+// tap_major (ggp_kernel's order): Wt[c + C*(f16 + 16*((b + TXc*a) + TYXc*fb))], f = 16*fb + f16 — reduction index
+// k = (fb*TYXc + tap)*16 + f16 instead of f*TYXc + tap.
 __global__ void dgrad_filter_kernel(const float* __restrict__ W, float* __restrict__ Wt, int F, int C, int Ky, int Kx, int cy,
                                     int cx, int sy, int sx, int TYc, int TXc, int tap_major) {
   const size_t total = (size_t)C * TXc * TYc * F;
@@ -930,10 +936,13 @@ __global__ void dgrad_filter_kernel(const float* __restrict__ W, float* __restri
     size_t r = i / C;
     int a, b, f;
     if (tap_major) {
-      f = r % F;
-      r /= F;
-      b = r % TXc;
-      a = r / TXc;
+      const int f16 = r % 16;
+      r /= 16;
+      const int tap = r % (TXc * TYc);
+      const int fb = r / (TXc * TYc);
+      f = fb * 16 + f16;
+      a = tap / TXc;
+      b = tap - a * TXc;
     } else {
       b = r % TXc;
       r /= TXc;
@@ -944,14 +953,16 @@ __global__ void dgrad_filter_kernel(const float* __restrict__ W, float* __restri
   }
 }
 
-// Forward filters in TAP-major reduction order for ggp_kernel: Wt[f + F*(c + C*tap)] = W[f + F*(tap + TYX*c)]  (tap = ky*Kx + kx).
+// Forward filters in ggp_kernel's reduction order: Wt[f + F*(c16 + 16*(tap + TYX*cb))] = W[f + F*(tap + TYX*(16*cb + c16))].
 __global__ void filter_tapmajor_kernel(const float* __restrict__ W, float* __restrict__ Wt, int F, int C, int TYX) {
   const size_t total = (size_t)F * C * TYX;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int f = i % F;
     size_t r = i / F;
-    const int c = r % C;
-    const int tap = r / C;
+    const int c16 = r % 16;
+    r /= 16;
+    const int tap = r % TYX;
+    const int c = (int)(r / TYX) * 16 + c16;
     Wt[i] = W[(size_t)f + (size_t)F * (tap + (size_t)TYX * c)];
   }
 }

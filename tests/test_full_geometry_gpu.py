@@ -211,7 +211,9 @@ def test_alexnet_conv_layer_at_full_size_n256(hip, layer):
     dx = hip.conv_down(g, dy, w)
     dw = hip.conv_outp(g, x, dy)
     a, b, c = _dot64(y, dy), _dot64(x, dx), _dot64(w, dw)
-    assert abs(a - b) / abs(a) < 1e-5 and abs(a - c) / abs(a) < 1e-5, (a, b, c)
+    # (44 M to 2.4 G random-sign products per inner product: the three fp32 results agree to a few 1e-6 of |a| after cancellation;
+    # a wrong tap, border or class shifts them by 1e-3 or more)
+    assert abs(a - b) / abs(a) < 3e-5 and abs(a - c) / abs(a) < 3e-5, (a, b, c)
     scale_y, scale_dx, scale_dw = float(np.abs(y).mean()), float(np.abs(dx).mean()), float(np.abs(dw).mean())
     for _ in range(48):
         n, f, oy, ox = rng.integers(g.N), rng.integers(g.F), rng.integers(g.My), rng.integers(g.Mx)
