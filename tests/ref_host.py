@@ -255,3 +255,25 @@ def slices_from_describe(layers, edges):
         out.append((off, n, chans[dst]))
         off += (n + 127) // 128 * 128
     return out, off
+
+
+def grad_check_criterion(a, n):
+    """GradChecker::GradCheck's running criterion, epsilon by epsilon, in the reference's float arithmetic INCLUDING its carry-over
+    of diff_sum and of the non-zero count between epsilons (grad_check.cc:41-64): [value after epsilon 0, after epsilon 1, ...] up to
+    and including the first value < 0.01 (where the reference stops).  NaN (0/0: every entry exactly zero) never passes."""
+    f32 = np.float32
+    diff_sum, non_zero, out = f32(0), 0, []
+    for row in n:
+        for k in range(a.size):
+            diff = f32(a[k]) - f32(row[k])
+            scale = (f32(a[k]) + f32(row[k])) / f32(2)
+            if not (scale == 0 and diff == 0):
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    diff_sum = f32(diff_sum + abs(diff / scale))
+                non_zero += 1
+        with np.errstate(divide="ignore", invalid="ignore"):
+            diff_sum = f32(diff_sum / f32(non_zero)) if non_zero else f32("nan")
+        out.append(float(diff_sum))
+        if diff_sum < 0.01:
+            break
+    return out
