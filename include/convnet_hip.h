@@ -133,7 +133,12 @@ int normalize_by_axis(cudamat* mat, cudamat* target, int axis);               /*
 
 /* ---- convolution: cudamat/cudamat_conv_gemm.cuh:36-49 ----------------------------------------------
  * targets = scaleTargets*targets + conv(...).  scaleTargets is the reference's 0/1 accumulate flag but
- * any value is honoured.  Implemented as implicit-GEMM on fp32 MFMA (no im2col buffer). */
+ * any value is honoured.  Implemented as implicit-GEMM on fp32 MFMA (no im2col buffer).
+ * Restrictions, the reference's own: num_groups == 1 (cudamat_conv_gemm.cu:599-600 asserts the same and the host
+ * never passes anything else, src/edge.cc:104), whole channel ranges (input/output_channel_begin/end = 0/0 or
+ * 0/channels), kernel_size_t <= 1.  These entries are void in the reference's ABI, so a violated restriction or a
+ * shape mismatch cannot be returned as a code: it prints "check failed: <condition>" with file:line to stderr and
+ * aborts, as the reference's assert() does.  The int-returning entries return the reference's error codes instead. */
 void convUpGemm(cudamat* images, cudamat* filters, cudamat* targets,
                 Shape4D* images_shape, Shape4D* filters_shape,
                 Shape4D* targets_shape, ConvDesc conv_desc,
