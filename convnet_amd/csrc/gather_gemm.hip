@@ -30,6 +30,7 @@
 namespace chip {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int BK = 16;  // reduction depth per LDS stage (gg_kernel)
@@ -198,6 +199,58 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT]
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// fp32 products on the bf16 matrix pipe (CONVNET_GG_SPLIT=1, opt-in): every operand value is split EXACTLY into three bf16
+// terms, x = h + m + l with h = rne8(x), m = rne8(x - h), l = x - h - m (the second residual has at most 8 significant bits), and
+// a*b is accumulated in fp32 as hh + hm + mh + hl + lh + mm by six v_mfma_f32_32x32x16_bf16.  The three dropped cross terms
+// (ml, lm, ll) are below 2^-23 of the product.  tools/split_gemm.hip measures it against double on conv4's reduction length:
+// max error 4.08 x 2^-24 of sum|ab| vs 4.55 x 2^-24 for v_mfma_f32_32x32x2_f32 on the same data — the fp32 accumulation rounding
+// dominates both.  Six 32-cycle instructions replace eight 64-cycle ones per 32 x 32 x 16 block: 2.67x the matrix-pipe rate,
+// paid for with ~5.5 VALU per operand element for the split.
+struct Split8 {
+  u32x4 h, m, l;   // 8 bf16 each: one A or B operand of the MFMA
+};
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void split8(const float (&x)[8], Split8& s) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = x[2 * q], x1 = x[2 * q + 1];
+    const unsigned H = pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(H << 16), r1 = x1 - __uint_as_float(H & 0xffff0000u);
+    const unsigned M = pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(M << 16), s1 = r1 - __uint_as_float(M & 0xffff0000u);
+    s.h[q] = H;
+    s.m[q] = M;
+    s.l[q] = pk_bf16(s0, s1);
+  }
+}
+__device__ __forceinline__ f32x16 mma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma_bf16(u32x4 a, u32x4 b, f32x4 c) {   // 16 x 16 tile, 32 k-slots: lane (li, lh) holds k = 8*lh .. 8*lh + 7
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// acc += a*b from the split operands: hh + hm + mh + hl + lh + mm, smallest first.  (Measured with m*l and l*m added — every dropped
+// term then is l*l <= 2^-32 of the product: 13-15 % slower on every layer, same parity results; not kept.)
+template <typename Acc>
+__device__ __forceinline__ Acc split_mac(const Split8& a, const Split8& b, Acc v) {
+  v = mma_bf16(a.m, b.m, v);
+  v = mma_bf16(a.h, b.l, v);
+  v = mma_bf16(a.l, b.h, v);
+  v = mma_bf16(a.h, b.m, v);
+  v = mma_bf16(a.m, b.h, v);
+  v = mma_bf16(a.h, b.h, v);
+  return v;
+}
+
 // Which tile does this block compute, and with which per-class fields?  Shared by gg_kernel and ggp_kernel.
 struct GGTile {
   const float* A;
@@ -250,7 +303,7 @@ __device__ __forceinline__ bool gg_select_tile(const GGParams& p, const GGClassT
 // O3 = the 3-blocks-per-CU build (launch bound 3 waves/SIMD + the k-row-major B stage that makes it fit): chosen by the
 // host only for launches with enough tiles to fill >= 2 rounds of 768 slots, where it gains 2-6 %; on ~512-tile launches
 // the blocks spread 3/1 over the CUs and it loses, so the 2-block build stays the default.
-template <int WR, int WC, int MT, int CW, bool A_KCONTIG, bool VEC, bool O3 = false>
+template <int WR, int WC, int MT, int CW, bool A_KCONTIG, bool VEC, bool O3 = false, bool SPLIT = false>
 __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGParams pin, const GGClassTable ct) {
   constexpr int NT = WR * WC * 64;
   constexpr int NTC = CW / 32, CW4 = CW / 4;
@@ -547,7 +600,46 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
     if constexpr (kTrace) tr1 = trace_clock();
     const float* as = As + buf * A_STAGE;
     const float* bs = Bs + buf * B_STAGE + (KM ? wc * CW : wc * BK * CW) + NTC * li;
-    if (!A_KCONTIG) {
+    if constexpr (SPLIT) {
+      // bf16-split products (Split8 below): the chunk is one MFMA deep; a lane's k-slot j is the LDS k-row the fp32 loop gives it
+      // in its j-th MFMA of the chunk (r-contiguous A: 2j + lh; k-contiguous A: 8*(j/4) + 4*lh + j%4), for both operands.
+      Split8 fa[MT];
+      fvec rb[8];
+      if constexpr (!A_KCONTIG) {
+        const float* ar = as + wr * MT * 32 + li;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          float x[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[j] = ar[(2 * j + lh) * ROWS + t * 32];
+          split8(x, fa[t]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rb[j] = *reinterpret_cast<const fvec*>(bs + (2 * j + lh) * BROW);
+      } else {
+        const float* ar = as + (wr * MT * 32 + li) * APITCH + 4 * lh;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const f32x4 v0 = ld4(ar + t * 32 * APITCH), v1 = ld4(ar + t * 32 * APITCH + 8);
+          const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          split8(x, fa[t]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rb[j] = *reinterpret_cast<const fvec*>(bs + (8 * (j / 4) + 4 * lh + (j & 3)) * BROW);
+      }
+#pragma unroll
+      for (int u = 0; u < NTC; ++u) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = rb[j][u];
+        Split8 fb;
+        split8(x, fb);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          acc[t][u] = split_mac(fa[t], fb, acc[t][u]);
+        }
+      }
+    } else if (!A_KCONTIG) {
       const float* ar = as + wr * MT * 32 + li;
       // fragments for step kk+1 are requested before the MFMAs of step kk
       float a[2][MT];
@@ -668,8 +760,8 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
 // (channel, tap_y, tap_x) is wave-uniform and lives in SGPRs; a lane's (wave-column, image quad) never changes.  Same MFMA order,
 // same epilogue, same tile selection as gg_kernel: results are bit-identical to it.
 // -------------------------------------------------------------------------------------------------
-template <int WR, int WC, int MT, int CW>
-__global__ __launch_bounds__(WR* WC * 64 + 64, 3) void ggp_kernel(const GGParams pin, const GGClassTable ct) {
+template <int WR, int WC, int MT, int CW, bool SPLIT = false>
+__global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && MT * (CW / 32) > 6) ? 2 : 3)) void ggp_kernel(const GGParams pin, const GGClassTable ct) {
   constexpr int NC = WR * WC * 64;   // consumer threads
   constexpr int NTC = CW / 32, CW4 = CW / 4;
   using fvec = __attribute__((ext_vector_type(NTC))) float;
@@ -845,6 +937,36 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 3) void ggp_kernel(const GGParams
   for (int c = 0; c < nchunks; ++c) {
     const float* ar = As + stage * A_STAGE + wr * MT * 32 + li;
     const float* bs = Bs + stage * B_STAGE + wc * CW + NTC * li;
+    if constexpr (SPLIT) {
+      // One chunk = one bf16 MFMA deep: MFMA k-slot (lh, j) takes LDS k-row 2j + lh for both operands (any common bijection
+      // of the chunk's 16 k-rows onto the instruction's 16 k-slots gives the same sum), i.e. the very reads of the fp32 loop.
+      float ra[MT][8];
+      fvec rb[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) ra[t][j] = ar[(2 * j + lh) * ROWS + t * 32];
+        rb[j] = *reinterpret_cast<const fvec*>(bs + (2 * j + lh) * BROW);
+      }
+      Split8 fa[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) split8(ra[t], fa[t]);
+#pragma unroll
+      for (int u = 0; u < NTC; ++u) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = rb[j][u];
+        Split8 fb;
+        split8(x, fb);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          acc[t][u] = split_mac(fa[t], fb, acc[t][u]);
+        }
+      }
+      stage = stage == ST - 1 ? 0 : stage + 1;
+      __syncthreads();
+      continue;
+    }
     float a[2][MT];
     fvec b4[2];
 #pragma unroll
@@ -999,7 +1121,7 @@ constexpr int WG_PITCH = WG_NB + 4;  // conflict-free ds_read_b128 across rows
 // tile; same FLOP/clk).  The 16-wide tiles let a 160 x 96 problem (conv1: 147 taps x 96 filters) split evenly
 // over 2x2 waves (80 x 48 each), which no arrangement of 32-wide tiles can: the 5-wave 32x32 config ran at 70
 // TFLOP/s with 10 waves on 4 SIMDs.
-template <int WM, int WN, int MT, int NTL, bool VEC, int TS>
+template <int WM, int WN, int MT, int NTL, bool VEC, int TS, bool SPLIT = false>
 __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int KT = WM * MT * TS;   // k-columns (D rows) per block
@@ -1195,6 +1317,32 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
     else if (prio == 1) __builtin_amdgcn_s_setprio(2);
     const float* ar = As + buf * A_STAGE + (wm * MT * TS + li) * PITCH;
     const float* br = Bs + buf * B_STAGE + (wn * NTL * TS + li) * PITCH;
+    if constexpr (SPLIT) {
+      // bf16-split products (see Split8): one MFMA is 8*LH images deep, a lane's 8 k-slots are the two b128 pieces the fp32 loop
+      // reads in iterations q = 2h and 2h+1 — the same images for both operands, so the sum is the same.
+#pragma unroll
+      for (int h = 0; h < WG_NB / (8 * LH); ++h) {
+        const int piece0 = 4 * ((LH * (2 * h) + lh) ^ swz), piece1 = 4 * ((LH * (2 * h + 1) + lh) ^ swz);
+        Split8 fa[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const f32x4 v0 = ld4(ar + t * TS * PITCH + piece0), v1 = ld4(ar + t * TS * PITCH + piece1);
+          const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          split8(x, fa[t]);
+        }
+#pragma unroll
+        for (int u = 0; u < NTL; ++u) {
+          const f32x4 v0 = ld4(br + u * TS * PITCH + piece0), v1 = ld4(br + u * TS * PITCH + piece1);
+          const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          Split8 fb;
+          split8(x, fb);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            acc[t][u] = split_mac(fa[t], fb, acc[t][u]);
+          }
+        }
+      }
+    } else
 #pragma unroll
     for (int q = 0; q < WG_NB / (4 * LH); ++q) {   // one b128 per lane = 4*LH images of the stage
       const int piece = 4 * ((LH * q + lh) ^ swz);
@@ -1350,6 +1498,18 @@ inline bool gg_producer_mode() {
   return v;
 }
 
+// CONVNET_GG_SPLIT=1 (opt-in): ggp_kernel's consumers run the products on the bf16 matrix pipe with exact three-way operand splits
+// (see Split8 above).  Off by default: the default path computes in v_mfma_f32_32x32x2_f32.
+inline bool gg_split_mode() {
+  static const bool v = [] { const char* e = getenv("CONVNET_GG_SPLIT"); return e && *e ? atoi(e) != 0 : false; }();
+  return v;
+}
+
+inline bool wg_split_mode() {   // CONVNET_WG_SPLIT overrides CONVNET_GG_SPLIT for wg_kernel alone (A/B runs)
+  static const bool v = [] { const char* e = getenv("CONVNET_WG_SPLIT"); return e && *e ? atoi(e) != 0 : gg_split_mode(); }();
+  return v;
+}
+
 // ggp_kernel exists for the tile shapes whose B stage has 64 sixteen-byte pieces per k-row (gg_run picks those for R > 32).
 inline bool ggp_shape_ok(int R, int KC) { return gg_producer_mode() && R > 32 && KC > 0 && KC % BK == 0 && getenv("CONVNET_GG_ROWS64") == nullptr; }
 
@@ -1404,16 +1564,26 @@ void gg_launch_classes(GGParams& p, GGClassTable& ct, bool vec) {
   }
   static const std::string kname_g = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ",rc>";
   static const std::string kname_p = "ggp_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ">";
-  const std::string& kname = p.KC > 0 ? kname_p : kname_g;
+  static const std::string kname_s = kname_p.substr(0, kname_p.size() - 1) + ",split>";
+  static const std::string kname_gs = kname_g.substr(0, kname_g.size() - 1) + ",split>";
+  const std::string& kname = p.KC > 0 ? (gg_split_mode() ? kname_s : kname_p) : ((vec && gg_split_mode()) ? kname_gs : kname_g);
   KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, (p.KC > 0 && p.nblk % WC == 0) ? 0.0 : t_exec);
   dim3 grid(end), block(WR * WC * 64);
   if (p.KC > 0) {
     CHIP_REQUIRE(vec && WC * (CW / 4) == 64);
     if constexpr (WC * (CW / 4) == 64) {
       const size_t lds3 = lds / 2 * 3;
-      allow_big_lds(ggp_kernel<WR, WC, MT, CW>, lds3);
-      hipLaunchKernelGGL((ggp_kernel<WR, WC, MT, CW>), grid, dim3(WR * WC * 64 + 64), lds3, stream(), p, ct);
+      if (gg_split_mode()) {
+        allow_big_lds(ggp_kernel<WR, WC, MT, CW, true>, lds3);
+        hipLaunchKernelGGL((ggp_kernel<WR, WC, MT, CW, true>), grid, dim3(WR * WC * 64 + 64), lds3, stream(), p, ct);
+      } else {
+        allow_big_lds(ggp_kernel<WR, WC, MT, CW>, lds3);
+        hipLaunchKernelGGL((ggp_kernel<WR, WC, MT, CW>), grid, dim3(WR * WC * 64 + 64), lds3, stream(), p, ct);
+      }
     }
+  } else if (vec && gg_split_mode()) {
+    allow_big_lds(gg_kernel<WR, WC, MT, CW, false, true, false, true>, lds);
+    hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, false, true, false, true>), grid, block, lds, stream(), p, ct);
   } else if (vec) {
     allow_big_lds(gg_kernel<WR, WC, MT, CW, false, true>, lds);
     hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, false, true>), grid, block, lds, stream(), p, ct);
@@ -1442,11 +1612,13 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   // 3 blocks per CU (768 slots) for launches with at least two such rounds of tiles; only the 128-row r-contiguous
   // vector build has the variant (it is the one whose register count sits between the 2- and 3-block limits).
   static const bool no_o3 = getenv("CONVNET_GG_NO_O3") != nullptr;
-  const bool o3 = !no_o3 && vec && !AK && WR == 2 && WC == 2 && MT == 2 && CW == 128 && tiles >= 2 * 768 && p.KC == 0;
+  const bool o3 = !no_o3 && !gg_split_mode() && vec && !AK && WR == 2 && WC == 2 && MT == 2 && CW == 128 && tiles >= 2 * 768 && p.KC == 0;
   int slots_launch = o3 ? 768 : kTargetBlocks;
   if constexpr (!AK && WC * (CW / 4) == 64) {
     if (p.KC > 0) {
-      static const int pslots = resident_slots(ggp_kernel<WR, WC, MT, CW>, WR * WC * 64 + 64, sizeof(float) * 3 * (A_STAGE + B_STAGE));
+      static const int pslots = gg_split_mode()
+                                    ? resident_slots(ggp_kernel<WR, WC, MT, CW, true>, WR * WC * 64 + 64, sizeof(float) * 3 * (A_STAGE + B_STAGE))
+                                    : resident_slots(ggp_kernel<WR, WC, MT, CW>, WR * WC * 64 + 64, sizeof(float) * 3 * (A_STAGE + B_STAGE));
       slots_launch = pslots;
     }
   }
@@ -1507,7 +1679,9 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   dim3 block(WR * WC * 64);
   static const std::string kname_g = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + "," + (AK ? "kc" : "rc") + ">";
   static const std::string kname_p = "ggp_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ">";
-  const std::string& kname = p.KC > 0 ? kname_p : kname_g;
+  static const std::string kname_s = kname_p.substr(0, kname_p.size() - 1) + ",split>";
+  static const std::string kname_gs = kname_g.substr(0, kname_g.size() - 1) + ",split>";
+  const std::string& kname = p.KC > 0 ? (gg_split_mode() ? kname_s : kname_p) : ((vec && gg_split_mode()) ? kname_gs : kname_g);
   {
     // ggp_kernel leaves out border taps when a tile is one pixel and owns its whole reduction: executed <= algorithmic then
     const bool skips = p.KC > 0 && splits == 1 && p.nblk % WC == 0;
@@ -1523,12 +1697,20 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
     if constexpr (!AK && WC * (CW / 4) == 64) {
       if (p.KC > 0) {
         const size_t lds3 = sizeof(float) * 3 * (A_STAGE + B_STAGE) + lds_pad;
-        allow_big_lds(ggp_kernel<WR, WC, MT, CW>, lds3);
-        hipLaunchKernelGGL((ggp_kernel<WR, WC, MT, CW>), grid, dim3(WR * WC * 64 + 64), lds3, stream(), p, kNoClasses);
+        if (gg_split_mode()) {
+          allow_big_lds(ggp_kernel<WR, WC, MT, CW, true>, lds3);
+          hipLaunchKernelGGL((ggp_kernel<WR, WC, MT, CW, true>), grid, dim3(WR * WC * 64 + 64), lds3, stream(), p, kNoClasses);
+        } else {
+          allow_big_lds(ggp_kernel<WR, WC, MT, CW>, lds3);
+          hipLaunchKernelGGL((ggp_kernel<WR, WC, MT, CW>), grid, dim3(WR * WC * 64 + 64), lds3, stream(), p, kNoClasses);
+        }
         donep = true;
       }
     }
     if (o3 || donep) {
+    } else if (vec && gg_split_mode()) {
+      allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, true, false, true>, lds);
+      hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, true, false, true>), grid, block, lds, stream(), p, kNoClasses);
     } else if (vec) {
       allow_big_lds(gg_kernel<WR, WC, MT, CW, AK, true>, lds);
       hipLaunchKernelGGL((gg_kernel<WR, WC, MT, CW, AK, true>), grid, block, lds, stream(), p, kNoClasses);
@@ -1611,10 +1793,16 @@ void wg_launch_cfg(WGParams& p, bool vec) {
   const int groups = splits > 64 ? 32 : 1;   // two-level reduce when the slab count dwarfs the tile
   p.partial = splits > 1 ? static_cast<float*>(workspace(sizeof(float) * total * (splits + (groups > 1 ? groups : 0)))) : nullptr;
   dim3 grid(((tiles * splits + 7) / 8) * 8), block(WM * WN * 64);
-  static const std::string kname = "wg_kernel<" + std::to_string(WM) + "," + std::to_string(WN) + "," + std::to_string(MT) + "," + std::to_string(NTL) + (TS == 16 ? ",x16>" : ">");
+  static const std::string kname_f = "wg_kernel<" + std::to_string(WM) + "," + std::to_string(WN) + "," + std::to_string(MT) + "," + std::to_string(NTL) + (TS == 16 ? ",x16>" : ">");
+  static const std::string kname_s = kname_f.substr(0, kname_f.size() - 1) + ",split>";
+  const bool split_products = vec && wg_split_mode();
+  const std::string& kname = split_products ? kname_s : kname_f;
   {
     KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, t_exec);
-    if (vec) {
+    if (split_products) {
+      allow_big_lds(wg_kernel<WM, WN, MT, NTL, true, TS, true>, lds);
+      hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, true, TS, true>), grid, block, lds, stream(), p);
+    } else if (vec) {
       allow_big_lds(wg_kernel<WM, WN, MT, NTL, true, TS>, lds);
       hipLaunchKernelGGL((wg_kernel<WM, WN, MT, NTL, true, TS>), grid, block, lds, stream(), p);
     } else {
