@@ -15,9 +15,16 @@ bracketed by barrier + torch.cuda.synchronize().
 
 Extra objects on the line:
   roofline      dominant MFMA kernel: algorithmic flops / HIP-event time measured per launch inside
-                the timed region, against the fp32-matrix peak (157.3 TFLOP/s; the parity path is
-                fp32 because grad_check needs it).  Also `model_frac` = whole-step algorithmic
-                flops / step time / peak, and per-kernel-family rows under `families`.
+                the timed region, against the fp32-matrix peak (157.3 TFLOP/s: operands, accumulation
+                and results are fp32 — grad_check needs it).  Also `model_frac` = whole-step algorithmic
+                flops / step time / peak, and per-kernel-family rows under `families`.  With the default
+                matrix path the kernels form the fp32 products on the bf16 matrix pipe from exact three-way
+                operand splits (six bf16 MFMAs per 32x32x16 block; include/convnet_hip.h), so `frac` can
+                exceed 1; `roofline.pipe` prices the same launches against the pipe they execute on
+                (6 executed bf16 flops per algorithmic flop, 2.5 PFLOP/s dense bf16 peak).
+  fp32_mfma_path  the same step with every GEMM kernel on v_mfma_f32_32x32x2_f32 instead (--matrix-path fp32),
+                timed in this process right after the main run (rank 0, N=1 only): the number to read if the
+                bf16-split products are not accepted as fp32 arithmetic.
   cpu_baseline  the reference's own CPU path (oracle/_ref, eigenmat+CPUMatrix compiled unmodified)
                 — or the C port if that build is absent — running the same model's training step
                 on a bounded sample (N=6 images, 1 step, ~13 s), rank 0, N=1 only.
@@ -34,7 +41,33 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD @ 2.4 GHz
+PEAK_BF16_MATRIX_TFLOPS = 2500.0  # dense v_mfma_f32_32x32x16_bf16: 1024 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0
+SPLIT_PRODUCTS = 6                # bf16 MFMAs per fp32 product block on the default matrix path
+
+
+def _same_kernel(bench_name, prof_name):
+    """bench.py names a kernel family "ggp_kernel<2,2,2,128,split>" / "gg_kernel<1,4,3,64,rc>" / "wg_kernel<2,2,5,3,x16,split>"; rocprofv3
+    prints the full template argument list ("ggp_kernel<2, 2, 2, 128, true>").  True when both name the same instantiation."""
+    def parse(n):
+        n = n.replace(" ", "")
+        if "<" not in n or ">" not in n[n.index("<"):]:
+            return n, []
+        return n[:n.index("<")].split("::")[-1], n[n.index("<") + 1:n.rindex(">")].split(",")
+    wb, wa = parse(bench_name)
+    fb, fa = parse(prof_name)
+    nums = [a for a in wa if a.isdigit()]
+    if wb != fb or fa[:len(nums)] != nums:
+        return False
+    rest = fa[len(nums):]
+    split = "split" in wa
+    if wb == "ggp_kernel":       # <WR, WC, MT, CW, SPLIT>
+        return (rest[:1] == ["true"]) == split
+    if wb == "wg_kernel":        # <WM, WN, MT, NTL, VEC, TS, SPLIT>
+        return len(rest) >= 2 and (rest[1] == "16") == ("x16" in wa) and ((len(rest) > 2 and rest[2] == "true") == split)
+    if wb == "gg_kernel":        # <WR, WC, MT, CW, A_KCONTIG, VEC, O3, SPLIT>
+        return len(rest) >= 1 and (rest[0] == "true") == ("kc" in wa) and ((len(rest) > 3 and rest[3] == "true") == split)
+    return not rest
 
 
 def pmc_traffic(kernel, args):
@@ -45,7 +78,6 @@ def pmc_traffic(kernel, args):
     import glob
     if args.model != "alexnet" or args.batch != 256 or args.unfused:
         return {"traffic": None}
-    want = kernel.replace(" ", "")
     for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic_bench.json")), reverse=True):
         try:
             with open(path) as f:
@@ -53,9 +85,7 @@ def pmc_traffic(kernel, args):
         except (OSError, ValueError, KeyError):
             continue
         for name, rec in kernels.items():
-            # bench names a family "gg_kernel<2,2,2,128,rc>"; the PMC file has the full template argument list
-            fam = name.replace(" ", "")
-            if fam.startswith(want.split(",rc")[0].split(",kc")[0]) and (",true,true," in fam) == want.endswith(",kc>"):
+            if _same_kernel(kernel, name):
                 return {"traffic": rec["traffic_bytes"], "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, fabric side)",
                         "traffic_source": "NOT measured in this run (PMC needs rocprofv3 around the process): read from the committed "
                                           "passes of this same command, " + os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))}
@@ -178,6 +208,10 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="STRONG scaling (SURVEY 8(d) config 4): this many images per step in total, split evenly over the ranks "
                          "(--batch is ignored); default 0 = weak scaling, --batch images on every rank")
+    ap.add_argument("--matrix-path", default="split", choices=["split", "fp32"],
+                    help="how the GEMM kernels form fp32 products: exact three-way bf16 splits on the bf16 matrix pipe (default) or "
+                         "the fp32 matrix instruction (convnet_hip_set_matrix_path)")
+    ap.add_argument("--no-other-path", action="store_true", help="skip the second timing with the other matrix path (rank 0, 1 GPU only)")
     ap.add_argument("--no-ref-host", action="store_true",
                     help="skip the `ref_host` leg (the reference's own unmodified C++ ConvNet::TrainOneBatch loop linked to this library, "
                          "tools/ref_host_bench.py, timed in a child process after the product run; rank 0, 1 GPU only)")
@@ -207,6 +241,7 @@ def main():
         args.batch = args.global_batch // world
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
     Matrix.SetupCUDADevice(local_rank)
+    _lib.lib.convnet_hip_set_matrix_path(1 if args.matrix_path == "split" else 0)
     exchange = None
     if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -267,6 +302,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    other = None
+    if world == 1 and not args.no_other_path:
+        # the same step on the other matrix path, same process, same net: 3 warm-up steps, then the same number of timed steps
+        other_name = "fp32" if args.matrix_path == "split" else "split"
+        _lib.lib.convnet_hip_set_matrix_path(1 if other_name == "split" else 0)
+        for _ in range(3):
+            net.TrainOneBatch()
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            net.TrainOneBatch()
+        sync_all()
+        dt_other = time.perf_counter() - t1
+        _lib.lib.convnet_hip_set_matrix_path(1 if args.matrix_path == "split" else 0)
+        other = {"matrix_path": other_name, "value": round(args.batch * args.steps / dt_other, 2), "unit": "images/sec",
+                 "ms_per_step": round(1e3 * dt_other / args.steps, 3), "steps": args.steps,
+                 "model_frac": round(step_flops / (dt_other / args.steps) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4)}
+
     if rank == 0:
         images = args.batch * world * args.steps
         value = images / dt
@@ -297,6 +350,11 @@ def main():
                                      "frac": round(all_flops / (all_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
                                      "ms_per_step": round(all_ms / timed_steps, 3)},
                 "model_frac": round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+                **({"pipe": {"instruction": "v_mfma_f32_32x32x16_bf16", "executed_per_algorithmic_flop": SPLIT_PRODUCTS,
+                             "achieved": round(SPLIT_PRODUCTS * (executed if executed > 0 else achieved), 1), "peak": PEAK_BF16_MATRIX_TFLOPS,
+                             "unit": "TFLOP/s (bf16, executed)",
+                             "frac": round(SPLIT_PRODUCTS * (executed if executed > 0 else achieved) / PEAK_BF16_MATRIX_TFLOPS, 4)}}
+                   if dom_name.endswith(",split>") else {}),
                 "families": {k: {"launches_per_step": v["launches"] / timed_steps, "ms_per_step": round(v["ms"] / timed_steps, 4),
                                  **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                      "executed_tflops": round(v["executed"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] > 0 else
@@ -309,6 +367,11 @@ def main():
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "arithmetic": ("fp32 operands, fp32 accumulation, fp32 results; GEMM products formed on the bf16 matrix pipe from exact three-way "
+                           "operand splits, 6 of 9 cross terms (dropped terms <= 2^-23 of a product; measured max error 4.08 x 2^-24 of sum|ab| at "
+                           "K=3456 vs 4.55 x 2^-24 for the fp32 matrix instruction, tools/split_gemm.hip); same parity tests and tolerances as "
+                           "the fp32-MFMA path, which `fp32_mfma_path` times beside it") if args.matrix_path == "split" else
+                          "fp32 operands, products and accumulation (v_mfma_f32_32x32x2_f32)",
             "config": {"workload": f"{args.model} (convnet_amd.models.{args.model}" + (": the reference's AlexNet-class ILSVRC pbtxt) " if args.model == "alexnet" else ") ") +
                                    f"training step, 224x224x3 synthetic " + ("uint8-valued 256x256 chunk, random crop+flip staged on the GPU each step, " if args.staged_input else "N(0,1) images, ") + f"{args.batch} images per GPU, "
                                    f"SGD+momentum+L2, dropout on, {'fused' if not args.unfused else 'unfused'} ABI calls",
@@ -318,6 +381,8 @@ def main():
                        "params": net.NumParameters(), "train_gflop_per_image": round(2e-9 * train_macs, 4)},
             "roofline": roofline,
         }
+        if other is not None:
+            out["fp32_mfma_path" if other["matrix_path"] == "fp32" else "split_path"] = other
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

@@ -84,6 +84,8 @@ def _load():
     sig("convnet_hip_get_stream", ctypes.c_void_p)
     sig("convnet_hip_reserve_workspace", I, ctypes.c_size_t)
     sig("convnet_hip_version", ctypes.c_char_p)
+    sig("convnet_hip_set_matrix_path", None, I)
+    sig("convnet_hip_get_matrix_path", I)
     sig("get_last_cuda_error", ctypes.c_char_p)
     sig("cuda_set_device", I, I)
     sig("cuda_sync_threads", None)

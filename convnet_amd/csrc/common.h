@@ -18,6 +18,8 @@ void* workspace(size_t bytes);
 void* workspace_aux(size_t bytes);   // independent second arena (dgrad filter images)
 // 256 bytes of device zeros (allocated once): where branch-free kernels point out-of-range loads.
 const float* zero_page();
+// 1: GEMM kernels form fp32 products on the bf16 matrix pipe from exact three-way operand splits (default); 0: fp32 MFMA.
+int matrix_path();
 void set_last_error(const char* msg);
 void note_kernel(const char* name, double flops, int blocks, int split_k);
 

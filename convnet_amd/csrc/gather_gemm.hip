@@ -761,7 +761,7 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
 // same epilogue, same tile selection as gg_kernel: results are bit-identical to it.
 // -------------------------------------------------------------------------------------------------
 template <int WR, int WC, int MT, int CW, bool SPLIT = false>
-__global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && MT * (CW / 32) > 6) ? 2 : 3)) void ggp_kernel(const GGParams pin, const GGClassTable ct) {
+__global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && MT * (CW / 32) >= 6) ? 2 : 3)) void ggp_kernel(const GGParams pin, const GGClassTable ct) {
   constexpr int NC = WR * WC * 64;   // consumer threads
   constexpr int NTC = CW / 32, CW4 = CW / 4;
   using fvec = __attribute__((ext_vector_type(NTC))) float;
@@ -934,39 +934,89 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && MT * (CW / 32) > 6) ? 
   // (Tried: closing barrier in front of the last k-step with the next chunk's first fragments requested right behind it — 123 vs
   // 130 TFLOP/s on conv4; the compiler's own placement, barrier after the first MFMA of the last k-step, is the better one.)
   int stage = 0;
+  if constexpr (SPLIT) {
+    // bf16-split products (Split8).  One chunk = one MFMA deep: k-slot (lh, j) of the instruction takes LDS k-row 2j + lh for both
+    // operands (any common bijection of the chunk's 16 k-rows onto the 16 k-slots gives the same sum) — the fp32 loop's reads.
+    // Software pipeline, because the split is ~5.5 VALU per operand element and VALU only overlaps MFMAs of the SAME wave here
+    // (one consumer wave per SIMD): column u's 6*MT MFMAs run with the split of column u+1 in their shadows; the chunk barrier
+    // sits in front of the LAST column, whose MFMAs cover the next chunk's A and column-0 reads and splits.  A fragments
+    // ping-pong between two register sets over a loop unrolled by two chunks.
+    auto read_a = [&](int st, float (&ra)[MT][8]) __attribute__((always_inline)) {
+      const float* ar = As + st * A_STAGE + wr * MT * 32 + li;
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ra[t][j] = ar[(2 * j + lh) * ROWS + t * 32];
+    };
+    auto read_col = [&](int st, int u, float (&x)[8]) __attribute__((always_inline)) {
+      const float* bs = Bs + st * B_STAGE + wc * CW + NTC * li + u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = bs[(2 * j + lh) * BROW];
+    };
+    Split8 fa0[MT], fa1[MT], fb[2];
+    float rc[8];   // raw column in flight
+    if (nchunks > 0) {
+      float ra[MT][8];
+      read_a(0, ra);
+      read_col(0, 0, rc);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) split8(ra[t], fa0[t]);
+      split8(rc, fb[0]);
+      read_col(0, 1 % NTC, rc);
+    }
+    // one chunk: fa = this chunk's A fragments, fan = where the next chunk's go; on entry fb[0] = column 0 split, rc = raw column 1
+    auto chunk = [&](Split8 (&fa)[MT], Split8 (&fan)[MT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u + 1 < NTC; ++u) {
+        __builtin_amdgcn_sched_barrier(0);
+        split8(rc, fb[(u + 1) & 1]);
+        if (u + 2 < NTC) read_col(stage, u + 2, rc);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t][u] = split_mac(fa[t], fb[u & 1], acc[t][u]);
+#pragma unroll
+        for (int i = 0; i < 6 * MT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      stage = stage == ST - 1 ? 0 : stage + 1;
+      __syncthreads();   // every consumer has read this chunk out of LDS; the producer has the next one landed
+      float ra[MT][8];
+      read_a(stage, ra);
+      read_col(stage, 0, rc);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) split8(ra[t], fan[t]);
+      split8(rc, fb[NTC & 1]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t][NTC - 1] = split_mac(fa[t], fb[(NTC - 1) & 1], acc[t][NTC - 1]);
+#pragma unroll
+      for (int i = 0; i < 6 * MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (44 * (MT + 1) + 6 * MT - 1) / (6 * MT), 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      read_col(stage, 1 % NTC, rc);
+    };
+    static_assert(NTC % 2 == 0, "column parity of fb is carried across chunks");
+    // (no condition between the two chunks of an iteration: the compiler would sink the next chunk's splits below it, out of the
+    // MFMA shadows; an odd chunk is peeled off in front instead.  The last chunk reads and splits one stage of garbage, unused.)
+    int c = 0;
+    if (nchunks & 1) {
+      chunk(fa0, fa1);
+      c = 1;
+    } else {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) fa1[t] = fa0[t];
+    }
+    for (; c < nchunks; c += 2) {
+      chunk(fa1, fa0);
+      chunk(fa0, fa1);
+    }
+  } else
   for (int c = 0; c < nchunks; ++c) {
     const float* ar = As + stage * A_STAGE + wr * MT * 32 + li;
     const float* bs = Bs + stage * B_STAGE + wc * CW + NTC * li;
-    if constexpr (SPLIT) {
-      // One chunk = one bf16 MFMA deep: MFMA k-slot (lh, j) takes LDS k-row 2j + lh for both operands (any common bijection
-      // of the chunk's 16 k-rows onto the instruction's 16 k-slots gives the same sum), i.e. the very reads of the fp32 loop.
-      float ra[MT][8];
-      fvec rb[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-#pragma unroll
-        for (int t = 0; t < MT; ++t) ra[t][j] = ar[(2 * j + lh) * ROWS + t * 32];
-        rb[j] = *reinterpret_cast<const fvec*>(bs + (2 * j + lh) * BROW);
-      }
-      Split8 fa[MT];
-#pragma unroll
-      for (int t = 0; t < MT; ++t) split8(ra[t], fa[t]);
-#pragma unroll
-      for (int u = 0; u < NTC; ++u) {
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = rb[j][u];
-        Split8 fb;
-        split8(x, fb);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-          acc[t][u] = split_mac(fa[t], fb, acc[t][u]);
-        }
-      }
-      stage = stage == ST - 1 ? 0 : stage + 1;
-      __syncthreads();
-      continue;
-    }
     float a[2][MT];
     fvec b4[2];
 #pragma unroll
@@ -1498,16 +1548,13 @@ inline bool gg_producer_mode() {
   return v;
 }
 
-// CONVNET_GG_SPLIT=1 (opt-in): ggp_kernel's consumers run the products on the bf16 matrix pipe with exact three-way operand splits
-// (see Split8 above).  Off by default: the default path computes in v_mfma_f32_32x32x2_f32.
-inline bool gg_split_mode() {
-  static const bool v = [] { const char* e = getenv("CONVNET_GG_SPLIT"); return e && *e ? atoi(e) != 0 : false; }();
-  return v;
-}
-
-inline bool wg_split_mode() {   // CONVNET_WG_SPLIT overrides CONVNET_GG_SPLIT for wg_kernel alone (A/B runs)
-  static const bool v = [] { const char* e = getenv("CONVNET_WG_SPLIT"); return e && *e ? atoi(e) != 0 : gg_split_mode(); }();
-  return v;
+// Which matrix instruction the GEMM kernels form their products with (matrix_path(), csrc/state.hip): 1 = bf16-split (default;
+// Split8 above), 0 = v_mfma_f32_32x32x2_f32.  CONVNET_GG_SPLIT=0/1 sets the initial value, convnet_hip_set_matrix_path() changes it
+// at run time (tests and bench.py run both); CONVNET_WG_SPLIT overrides it for wg_kernel alone (A/B runs).
+inline bool gg_split_mode() { return matrix_path() != 0; }
+inline bool wg_split_mode() {
+  static const int v = [] { const char* e = getenv("CONVNET_WG_SPLIT"); return e && *e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  return v < 0 ? gg_split_mode() : v != 0;
 }
 
 // ggp_kernel exists for the tile shapes whose B stage has 64 sixteen-byte pieces per k-row (gg_run picks those for R > 32).
@@ -1616,10 +1663,9 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   int slots_launch = o3 ? 768 : kTargetBlocks;
   if constexpr (!AK && WC * (CW / 4) == 64) {
     if (p.KC > 0) {
-      static const int pslots = gg_split_mode()
-                                    ? resident_slots(ggp_kernel<WR, WC, MT, CW, true>, WR * WC * 64 + 64, sizeof(float) * 3 * (A_STAGE + B_STAGE))
-                                    : resident_slots(ggp_kernel<WR, WC, MT, CW>, WR * WC * 64 + 64, sizeof(float) * 3 * (A_STAGE + B_STAGE));
-      slots_launch = pslots;
+      static const int pslots_s = resident_slots(ggp_kernel<WR, WC, MT, CW, true>, WR * WC * 64 + 64, sizeof(float) * 3 * (A_STAGE + B_STAGE));
+      static const int pslots_f = resident_slots(ggp_kernel<WR, WC, MT, CW>, WR * WC * 64 + 64, sizeof(float) * 3 * (A_STAGE + B_STAGE));
+      slots_launch = gg_split_mode() ? pslots_s : pslots_f;
     }
   }
   // Split-K factor by wave quantisation: every block of a launch takes the same time, so a grid of b

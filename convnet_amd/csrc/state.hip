@@ -17,6 +17,15 @@ ConvnetHipKernelInfo g_info = {"none", 0.0, 0, 1};
 
 hipStream_t stream() { return g_stream; }
 
+int g_matrix_path = -1;   // -1: not decided yet (first use reads CONVNET_GG_SPLIT; default 1)
+int matrix_path() {
+  if (g_matrix_path < 0) {
+    const char* e = getenv("CONVNET_GG_SPLIT");
+    g_matrix_path = (e && *e) ? (atoi(e) != 0 ? 1 : 0) : 1;
+  }
+  return g_matrix_path;
+}
+
 // Scratch arenas are per stream: a host that drives a second stream through convnet_hip_set_stream (e.g.
 // optimizer updates beside the backward pass) gets its own split-K slabs, so concurrent launches on two
 // streams never share a base pointer.  Grow-only; growth waits for that stream's in-flight users first and
@@ -142,7 +151,9 @@ int convnet_hip_reserve_workspace(size_t bytes) {
   return 0;
 }
 
-const char* convnet_hip_version(void) { return "convnet_hip 0.1 (gfx950, fp32 MFMA)"; }
+const char* convnet_hip_version(void) { return "convnet_hip 0.2 (gfx950; fp32 products via bf16-split or fp32 MFMA)"; }
+void convnet_hip_set_matrix_path(int path) { chip::g_matrix_path = path != 0 ? 1 : 0; }
+int convnet_hip_get_matrix_path(void) { return chip::matrix_path(); }
 const char* get_last_cuda_error(void) { return g_last_error.c_str(); }
 
 int cuda_set_device(int deviceId) { return hipSetDevice(deviceId) == hipSuccess ? 0 : CUDA_ERROR; }

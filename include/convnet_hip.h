@@ -85,6 +85,17 @@ void convnet_hip_set_stream(void* hip_stream);       /* hipStream_t; NULL = defa
 void* convnet_hip_get_stream(void);
 int convnet_hip_reserve_workspace(size_t bytes);     /* optional pre-size (avoids growth mid-run) */
 const char* convnet_hip_version(void);
+/* How the GEMM-shaped kernels (conv fprop / dgrad / wgrad, dot) form their fp32 products.  Operands, accumulation and results
+ * are fp32 either way.
+ *   1 (default): on the bf16 matrix pipe from EXACT three-way splits x = h + m + l (each term a bf16), six of the nine cross
+ *     products per operand pair (hh, hm, mh, hl, lh, mm; the dropped ml, lm, ll are <= 2^-23 of a product), fp32 accumulate in
+ *     v_mfma_f32_32x32x16_bf16.  Measured error against double on a K = 3456 reduction: 4.08 x 2^-24 of sum|ab| (max), vs 4.55 x
+ *     2^-24 for path 0 on the same data (tools/split_gemm.hip) — accumulation rounding dominates both.  Non-finite inputs: an
+ *     infinite operand yields NaN (inf - inf in the split) where path 0 yields inf.
+ *   0: v_mfma_f32_32x32x2_f32 (round 1's path; exact fp32 products).
+ * Initial value: environment CONVNET_GG_SPLIT (0/1), else 1.  May be changed between calls at any time. */
+void convnet_hip_set_matrix_path(int path);
+int convnet_hip_get_matrix_path(void);
 const char* get_last_cuda_error(void);               /* cudamat.cuh:109 */
 int cuda_set_device(int deviceId);                   /* cudamat.cuh:116 */
 void cuda_sync_threads(void);                        /* cudamat.cuh:123 — synchronises the current stream */

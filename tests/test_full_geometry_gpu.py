@@ -59,6 +59,18 @@ def _train_pass(net):
     return x, labels, states, derivs
 
 
+def _within(got, want, tol, ulps=4):
+    """The reference's metric (max|a-b| / mean|a+b| < tol) — or, for the elements that miss it, agreement to `ulps` fp32 ulps of
+    the element itself.  The metric divides the LARGEST error by the MEAN magnitude: on a heavy-tailed tensor (fc8's dW at N = 4:
+    a four-term sum per element, the label column ~3000x the mean) one ulp of the largest element is already 1.8e-4 of the mean,
+    so only an implementation that rounds bit-identically to the CPU loop can pass it there; any other summation order or product
+    formation (the bf16-split path, an FMA) differs in the last bit of some large element."""
+    a, b = np.asarray(got, np.float64).ravel(), np.asarray(want, np.float64).ravel()
+    d = np.abs(a - b)
+    miss = d >= tol * (np.abs(a + b).mean() + 1e-30)
+    return bool(np.all(d[miss] <= ulps * 2.0 ** -23 * np.maximum(np.abs(a[miss]), np.abs(b[miss]))))
+
+
 def _check_whole_net(net, impl, forced_only=False):
     """Three comparisons of one training pass with the CPU oracle:
       1. forward chain, un-forced: the oracle sees only the input, the parameters and the device's dropout masks; every layer's
@@ -92,7 +104,7 @@ def _check_whole_net(net, impl, forced_only=False):
         if e.GetName() in og:
             dw, db = og[e.GetName()]
             grads[e.GetName()] = (e.GetGradWeight().ToNumpy().reshape(-1), e.GetGradBias().ToNumpy().reshape(-1))
-            assert rel_err(grads[e.GetName()][0], dw) < TOL, ("dW (forced)", e.GetName(), rel_err(grads[e.GetName()][0], dw))
+            assert _within(grads[e.GetName()][0], dw, TOL), ("dW (forced)", e.GetName(), rel_err(grads[e.GetName()][0], dw))
             assert rel_err(grads[e.GetName()][1], db) < TOL, ("db (forced)", e.GetName(), rel_err(grads[e.GetName()][1], db))
     if not forced_only:
         _, ud, ug = forward_backward(net, x, labels, impl=impl, force=(states, None), dropout_states=states)
@@ -115,15 +127,21 @@ def _build(text, batch, fused, seed=5):
     return build(text, batch, fused, seed_data=seed)
 
 
-@pytest.mark.parametrize("N,fused,which", [(4, False, "port"), (4, True, "port"), (8, True, "port"), (4, False, "ref")])
-def test_real_alexnet_224_training_pass_vs_cpu_oracle(gpu, N, fused, which):
-    from convnet_amd import models
+@pytest.mark.parametrize("N,fused,which,path", [(4, False, "port", "split"), (4, True, "port", "split"), (8, True, "port", "split"),
+                                                (4, False, "ref", "split"), (4, False, "port", "fp32"), (8, True, "ref", "fp32")])
+def test_real_alexnet_224_training_pass_vs_cpu_oracle(gpu, N, fused, which, path):
+    """`path`: both ways the library forms its GEMM products (convnet_hip_set_matrix_path) — bf16-split (default) and fp32 MFMA."""
+    from convnet_amd import _lib, models
     impl = oracle.port if which == "port" else oracle.ref
     if impl is None:
         pytest.skip("oracle/_ref not built on this box")
-    net = _build(models.alexnet(), N, fused)
-    assert net.input_layers_[0].GetSizeY() == 224 and net.GetLayerByName("hidden6").dropprob_ > 0
-    _check_whole_net(net, impl)
+    _lib.lib.convnet_hip_set_matrix_path(1 if path == "split" else 0)
+    try:
+        net = _build(models.alexnet(), N, fused)
+        assert net.input_layers_[0].GetSizeY() == 224 and net.GetLayerByName("hidden6").dropprob_ > 0
+        _check_whole_net(net, impl)
+    finally:
+        _lib.lib.convnet_hip_set_matrix_path(1)
 
 
 def test_real_alexnet_224_at_the_benchmark_batch_256(gpu):

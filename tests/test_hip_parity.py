@@ -29,11 +29,22 @@ def hip():
     return HipImpl()
 
 
+@pytest.fixture(params=["split", "fp32"])
+def matrix_path(request, hip):
+    """Both ways the GEMM kernels form their fp32 products (include/convnet_hip.h: convnet_hip_set_matrix_path): on the bf16
+    matrix pipe from exact three-way operand splits (the default) and with the fp32 matrix instruction.  Same tolerances."""
+    from convnet_amd import _lib
+    L = _lib.lib
+    L.convnet_hip_set_matrix_path(1 if request.param == "split" else 0)
+    yield request.param
+    L.convnet_hip_set_matrix_path(1)
+
+
 def rnd(rng, shape):
     return rng.standard_normal(shape).astype(np.float32)
 
 
-def test_golden_vectors(hip):
+def test_golden_vectors(hip, matrix_path):
     golden = dict(np.load(GOLDEN))
     got = compute_all(hip)
     assert set(got) == set(golden)
@@ -76,7 +87,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("g", CONV_CASES, ids=lambda g: f"N{g.N}C{g.C}H{g.H}F{g.F}k{g.Ky}s{g.sy}p{g.pady}")
-def test_conv_up_down_outp_vs_oracle(hip, g):
+def test_conv_up_down_outp_vs_oracle(hip, matrix_path, g):
     rng = np.random.default_rng(11)
     x, w, dy = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape()), rnd(rng, g.out_shape())
     for st in (0.0, 1.0):
@@ -89,7 +100,7 @@ def test_conv_up_down_outp_vs_oracle(hip, g):
         assert rel_err(hip.conv_outp(g, x, dy, t0.copy(), st, so), oracle.port.conv_outp(g, x, dy, t0.copy(), st, so)) < TOL
 
 
-def test_conv_fused_bias_relu_equals_unfused_sequence(hip):
+def test_conv_fused_bias_relu_equals_unfused_sequence(hip, matrix_path):
     g = Geom(N=16, C=8, H=9, W=9, F=24, Ky=3, Kx=3, pady=1, padx=1)
     rng = np.random.default_rng(12)
     x, w, b = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape()), rnd(rng, (g.F,))
@@ -148,7 +159,7 @@ def test_response_norm_vs_oracle(hip, shape, size_f, blocked):
 
 
 @pytest.mark.parametrize("N,D,F", [(256, 1152, 1000), (100, 1152, 10), (9, 37, 11), (128, 4096, 512), (32, 260, 132)])
-def test_fc_dot_three_forms_vs_oracle(hip, N, D, F):
+def test_fc_dot_three_forms_vs_oracle(hip, matrix_path, N, D, F):
     rng = np.random.default_rng(15)
     x, w, dy = rnd(rng, (D, N)), rnd(rng, (D, F)) * 0.1, rnd(rng, (F, N))
     for beta in (0.0, 1.0):
@@ -176,7 +187,7 @@ def test_dot_full_contract_all_transposes_and_alpha(hip, m, n, k):
                 assert rel_err(got, want) < TOL, (ta, tb, beta, alpha, rel_err(got, want))
 
 
-def test_linearity_and_adjointness_at_full_alexnet_conv3_size(hip):
+def test_linearity_and_adjointness_at_full_alexnet_conv3_size(hip, matrix_path):
     """Size-independent properties at BASELINE's full layer size (N=256), where the CPU oracle would
     take minutes: <conv(x,w), dy> == <x, convT(dy,w)> == <w, wgrad(x,dy)> (the three kernels are
     mutually adjoint), checked in float64 on the host."""
@@ -319,7 +330,7 @@ def test_event_trio_orders_two_streams(hip):
 @pytest.mark.gpu
 @pytest.mark.parametrize("g", [CONV_CASES[0], CONV_CASES[1], CONV_CASES[4], CONV_CASES[5], CONV_CASES[6], CONV_CASES[10]],
                          ids=lambda g: f"N{g.N}C{g.C}F{g.F}K{g.K}")
-def test_conv_outp_bias_equals_outp_plus_two_step_sum(hip, g):
+def test_conv_outp_bias_equals_outp_plus_two_step_sum(hip, matrix_path, g):
     """convOutpBias = convOutp + the shared-bias gradient (conv_edge.cc:210-221), whether the bias row rides in the
     weight-gradient tile (K+1 fits the padded tile: conv1's 147+1 <= 160) or the library falls back to a column sum
     (K a multiple of the tile: conv3's 2304)."""
@@ -359,7 +370,7 @@ def test_input_staging_is_bit_exact_vs_oracle_incl_ragged_sizes(hip):
 
 
 @pytest.mark.gpu
-def test_conv_up_tail_split_more_tiles_than_slots(hip):
+def test_conv_up_tail_split_more_tiles_than_slots(hip, matrix_path):
     """648 block tiles on 512 resident slots: tiles 512..647 are computed as K-split pieces whose raw sums
     gg_tail_fix_kernel adds in fixed order before the normal epilogue (accumulate / bias / ReLU).  Same result as the
     whole-K path: CONVNET_GG_NO_TAIL_SPLIT is the A/B switch used when measuring."""
@@ -392,7 +403,7 @@ def _random_geoms(seed, count):
 
 
 @pytest.mark.gpu
-def test_conv_random_geometries_vs_oracle(hip):
+def test_conv_random_geometries_vs_oracle(hip, matrix_path):
     """Seeded sweep over 48 random geometries (rectangular images / kernels / strides, paddings, every row-tile class,
     vector and scalar paths, accumulate on and off) for fprop, dgrad, wgrad and the fused wgrad+bias."""
     from hip_adapter import conv_outp_bias
@@ -438,7 +449,7 @@ def test_pooling_random_square_geometries_vs_oracle(hip):
 
 
 @pytest.mark.gpu
-def test_conv_up_three_blocks_per_cu_build(hip):
+def test_conv_up_three_blocks_per_cu_build(hip, matrix_path):
     """1600 block tiles (>= 2 rounds of 768 slots) selects the 3-blocks-per-CU build of gg_kernel (k-row-major B stage,
     wave-uniform tap decode); 1600 = 2 x 768 + 64 also leaves a tail that is K-split.  Padding, accumulate, bias + ReLU."""
     g = Geom(N=256, C=36, H=40, W=40, F=128, Ky=3, Kx=3, pady=1, padx=1)
@@ -452,7 +463,7 @@ def test_conv_up_three_blocks_per_cu_build(hip):
 
 
 @pytest.mark.gpu
-def test_conv_down_mask_with_tail_split(hip):
+def test_conv_down_mask_with_tail_split(hip, matrix_path):
     """Stride-1 dgrad with the fused ReLU' + dropout' epilogue (convDownMask) at 648 tiles: whole-K blocks and K-split tail
     tiles must apply accumulate -> mask -> post-scale identically."""
     from convnet_amd.matrix import Matrix

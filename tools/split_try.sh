@@ -1,11 +1,14 @@
 #!/bin/bash
-# A/B of the bf16-split products (CONVNET_GG_SPLIT=1) against the default fp32-MFMA path, one gpurun call.
+# full GPU suite + bench at the default (bf16-split) matrix path, one gpurun call.
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/split
 mkdir -p $O
-export CONVNET_GG_SPLIT=1
-CONVNET_SPLIT_TERMS=8 timeout 600 python -m pytest tests/test_full_geometry_gpu.py -q -m gpu -k "training_pass" > $O/geom_split8.log 2>&1; tail -5 $O/geom_split8.log
-CONVNET_SPLIT_TERMS=6 timeout 120 python tools/layer_bench.py > $O/layer_split6.txt 2>&1
-CONVNET_SPLIT_TERMS=8 timeout 120 python tools/layer_bench.py > $O/layer_split8.txt 2>&1
-paste <(grep -v amdgpu $O/layer_split6.txt | grep -v "reduce\|filter_\|tail_fix" | awk '{print $1,$2,$3,$4,$5}') <(grep -v amdgpu $O/layer_split8.txt | grep -v "reduce\|filter_\|tail_fix" | awk '{print $4,$5}') | head -40
-CONVNET_SPLIT_TERMS=8 timeout 200 python bench.py --no-ref-host > $O/bench_split8.json 2> $O/bench_split8.err; cut -c1-300 $O/bench_split8.json
+timeout 900 python -m pytest tests -q -m gpu > $O/suite.log 2>&1; tail -12 $O/suite.log
+timeout 400 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-250 $O/bench.json; python - <<'PY'
+import json
+d=json.load(open('gpurun_out/split/bench.json'))
+r=d['roofline']
+print({k:r[k] for k in ('kernel','achieved','frac','model_frac','pipe','all_mfma_kernels')})
+print(d.get('fp32_mfma_path'), d.get('ref_host'), d.get('cpu_baseline',{}).get('value'))
+for k,v in list(r['families'].items())[:14]: print(k, v)
+PY
