@@ -1369,29 +1369,43 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
     const float* br = Bs + buf * B_STAGE + (wn * NTL * TS + li) * PITCH;
     if constexpr (SPLIT) {
       // bf16-split products (see Split8): one MFMA is 8*LH images deep, a lane's 8 k-slots are the two b128 pieces the fp32 loop
-      // reads in iterations q = 2h and 2h+1 — the same images for both operands, so the sum is the same.
-#pragma unroll
-      for (int h = 0; h < WG_NB / (8 * LH); ++h) {
+      // reads in iterations q = 2h and 2h+1 — the same images for both operands, so the sum is the same.  The stage is walked as
+      // H * NTL column steps (half-stage h, filter tile u) of 6*MT MFMAs each; the split of the NEXT step's operands (its B tile,
+      // and the A tiles when it opens a new half) is pinned into the shadows of this step's MFMAs.
+      constexpr int H = WG_NB / (8 * LH), STEPS = H * NTL;
+      auto split_row = [&](const float* rowp, int h, Split8& o) __attribute__((always_inline)) {
         const int piece0 = 4 * ((LH * (2 * h) + lh) ^ swz), piece1 = 4 * ((LH * (2 * h + 1) + lh) ^ swz);
-        Split8 fa[MT];
+        const f32x4 v0 = ld4(rowp + piece0), v1 = ld4(rowp + piece1);
+        const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        split8(x, o);
+      };
+      Split8 fa[2][MT], fb[2];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-          const f32x4 v0 = ld4(ar + t * TS * PITCH + piece0), v1 = ld4(ar + t * TS * PITCH + piece1);
-          const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          split8(x, fa[t]);
+      for (int t = 0; t < MT; ++t) split_row(ar + t * TS * PITCH, 0, fa[0][t]);
+      split_row(br, 0, fb[0]);
+      static_for<0, STEPS>([&](auto S) __attribute__((always_inline)) {
+        constexpr int s = decltype(S)::value, h = s / NTL, u = s % NTL;
+        constexpr bool more = s + 1 < STEPS;
+        constexpr int h2 = (s + 1) / NTL, u2 = (s + 1) % NTL;
+        constexpr bool new_half = more && u2 == 0;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (new_half) {
+#pragma unroll
+          for (int t = 0; t < MT; ++t) split_row(ar + t * TS * PITCH, h2, fa[h2 & 1][t]);
         }
+        if constexpr (more) split_row(br + u2 * TS * PITCH, h2, fb[(s + 1) & 1]);
 #pragma unroll
-        for (int u = 0; u < NTL; ++u) {
-          const f32x4 v0 = ld4(br + u * TS * PITCH + piece0), v1 = ld4(br + u * TS * PITCH + piece1);
-          const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          Split8 fb;
-          split8(x, fb);
+        for (int t = 0; t < MT; ++t) acc[t][u] = split_mac(fa[h & 1][t], fb[s & 1], acc[t][u]);
+        if constexpr (more) {
+          constexpr int valu = 46 * (new_half ? MT + 1 : 1), per = (valu + 6 * MT - 1) / (6 * MT);
 #pragma unroll
-          for (int t = 0; t < MT; ++t) {
-            acc[t][u] = split_mac(fa[t], fb, acc[t][u]);
+          for (int i = 0; i < 6 * MT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
           }
         }
-      }
+      });
+      __builtin_amdgcn_sched_barrier(0);
     } else
 #pragma unroll
     for (int q = 0; q < WG_NB / (4 * LH); ++q) {   // one b128 per lane = 4*LH images of the stage
@@ -1668,6 +1682,9 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
       slots_launch = gg_split_mode() ? pslots_s : pslots_f;
     }
   }
+  // FLOP/s of one resident block, for the two estimates below: fp32 MFMA = half a CU (64 FLOP/clk/SIMD, 2 blocks per CU) at 80 %;
+  // bf16-split = the measured ~190 TFLOP/s-equivalent of a full chip over its resident blocks.
+  const double block_rate = gg_split_mode() ? 190e12 / slots_launch : 64.0 * 4 * 2.2e9 * 0.8 / 2;
   // Split-K factor by wave quantisation: every block of a launch takes the same time, so a grid of b
   // blocks on `slots` resident-block slots runs ceil(b/slots) rounds and wastes the empty part of the
   // last one (338 tiles on 512 slots = 66 % busy; 3 K-splits = 1014 blocks = 99 %).  Pick the split with
@@ -1680,7 +1697,7 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
     double best_t = 1e30;
     for (int sp = 1; sp <= 16 && kchunks / sp >= 8; ++sp) {
       const double rounds = std::ceil(tiles * (double)sp / slots);
-      double t = rounds * (flops / sp) / (64.0 * 4 * 2.2e9 * 0.8 / 2);     // block time on half a CU (64 FLOP/clk/SIMD) at 80 %
+      double t = rounds * (flops / sp) / block_rate;
       if (sp > 1) t += sizeof(float) * (double)dst_elems * (2.0 * sp + 1) / 4.0e12 + 4e-6;
       if (t < best_t * 0.97) {
         best_t = t;
@@ -1702,7 +1719,7 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   if (!no_tail && splits == 1 && dst_elems > 0 && tiles > slots && tiles % slots != 0 && kchunks >= 32) {
     const int full = (tiles / slots) * slots, rem = tiles - full;
     const double tile_bytes = sizeof(float) * (double)ROWS * WC * CW;
-    const double t_round = 2.0 * ROWS * (WC * (double)CW) * (double)p.K / (64.0 * 4 * 2.2e9 * 0.8 / 2);   // one whole-K block
+    const double t_round = 2.0 * ROWS * (WC * (double)CW) * (double)p.K / block_rate;   // one whole-K block
     double best = 0.95;   // cost of the last round today = 1 round; require a 5 % gain on it
     int best_s = 1;
     for (int s = 2; s <= 8 && kchunks / s >= 8; ++s) {
