@@ -63,6 +63,7 @@ struct GGParams {
   int lda;            // A[r + lda*k] (r-contiguous) or A[k + lda*r] (k-contiguous)
   int GX, G;          // output pixel grid of this launch: G = GY*GX pixels, m = oy*GX + ox
   int TX, TYX;        // taps: k = ch*TYX + a*TX + b   (channel-major, KC == 0)
+  int apre;           // ggp_kernel split build: A is the pre-split bf16-plane image of the bank (split_planes_kernel)
   int KC;             // > 0 (ggp_kernel): reduction order k = ((cb*TYX + tap)*BK + c16, channel ch = cb*BK + c16 of KC — every chunk of BK
                       // k-rows is ONE tap of one 16-channel block, taps innermost — over a filter bank re-laid to match
   int SH, SW;         // source image
@@ -760,16 +761,21 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
 // (channel, tap_y, tap_x) is wave-uniform and lives in SGPRs; a lane's (wave-column, image quad) never changes.  Same MFMA order,
 // same epilogue, same tile selection as gg_kernel: results are bit-identical to it.
 // -------------------------------------------------------------------------------------------------
-template <int WR, int WC, int MT, int CW, bool SPLIT = false>
-__global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && MT * (CW / 32) >= 6) ? 2 : 3)) void ggp_kernel(const GGParams pin, const GGClassTable ct) {
+// APRE (with SPLIT): the A operand arrives ALREADY split — split_planes_kernel turned the re-laid filter bank into bf16 planes
+// [chunk][plane h/m/l][k-group lh][row][8 x bf16 = k-slots j of k-rows 2j + lh], so a lane's A fragment of one plane is ONE ds_read_b128
+// and a third of the loop's split VALU is gone (the bank is a few MB and is rewritten every call anyway).
+template <int WR, int WC, int MT, int CW, bool SPLIT = false, bool APRE = false>
+__global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 || (MT * (CW / 32) == 6 && !APRE))) ? 2 : 3)) void ggp_kernel(const GGParams pin, const GGClassTable ct) {
+  static_assert(!APRE || SPLIT, "pre-split A is a variant of the bf16-split build");
   constexpr int NC = WR * WC * 64;   // consumer threads
   constexpr int NTC = CW / 32, CW4 = CW / 4;
   using fvec = __attribute__((ext_vector_type(NTC))) float;
   constexpr int ROWS = WR * MT * 32;
-  constexpr int A_STAGE = BK * ROWS, B_STAGE = WC * BK * CW, ST = 3;
-  constexpr int NA = BK * (ROWS / 4) / 64, NB = WC * BK * CW4 / 64;   // producer wave-instructions per chunk
+  // A stage in floats: 16 k-rows x ROWS fp32, or (APRE) 3 planes x 2 k-groups x ROWS x 16 bytes
+  constexpr int A_STAGE = APRE ? 6 * ROWS * 4 : BK * ROWS, B_STAGE = WC * BK * CW, ST = 3;
+  constexpr int NA = A_STAGE / 4 / 64, NB = WC * BK * CW4 / 64;   // producer wave-instructions per chunk (16 bytes per lane)
   static_assert(WC * CW4 == 64, "one producer instruction = one k-row of the B stage");
-  static_assert((BK * (ROWS / 4)) % 64 == 0 && NB == BK, "whole wave-instructions");
+  static_assert((A_STAGE / 4) % 64 == 0 && NB == BK, "whole wave-instructions");
   constexpr int BROW = WC * CW;      // floats between consecutive k-rows of the B stage
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                  // [ST][A_STAGE]
@@ -869,12 +875,18 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && MT * (CW / 32) >= 6) ?
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const int idx = lane + 64 * it;
-      const int krow = idx / (ROWS / 4), q = idx - krow * (ROWS / 4);
-      a_ok[it] = r0 + 4 * q < R;
-      a_off[it] = (unsigned)(krow * lda + r0 + 4 * q) * 4u;
+      if constexpr (APRE) {
+        const int pl = idx / ROWS, row = idx - pl * ROWS;   // pl = plane*2 + k-group; 16 bytes per (pl, row)
+        a_ok[it] = r0 + row < R;
+        a_off[it] = (unsigned)(pl * lda + r0 + row) * 16u;
+      } else {
+        const int krow = idx / (ROWS / 4), q = idx - krow * (ROWS / 4);
+        a_ok[it] = r0 + 4 * q < R;
+        a_off[it] = (unsigned)(krow * lda + r0 + 4 * q) * 4u;
+      }
     }
     const char* const abase0 = reinterpret_cast<const char*>(T.A);
-    const size_t a_chunk_bytes = (size_t)lda * BK * 4;   // one chunk of filter rows; chunk index = cb*TYX + tap
+    const size_t a_chunk_bytes = (size_t)lda * (APRE ? 96 : BK * 4);   // one chunk of filter rows; chunk index = cb*TYX + tap
 
     auto issue = [&](int stage) __attribute__((always_inline)) {
       const char* const abase = abase0 + a_chunk_bytes * (size_t)(cb * TYX + ta * TX + tb);   // wave-uniform
@@ -941,12 +953,26 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && MT * (CW / 32) >= 6) ?
     // (one consumer wave per SIMD): column u's 6*MT MFMAs run with the split of column u+1 in their shadows; the chunk barrier
     // sits in front of the LAST column, whose MFMAs cover the next chunk's A and column-0 reads and splits.  A fragments
     // ping-pong between two register sets over a loop unrolled by two chunks.
-    auto read_a = [&](int st, float (&ra)[MT][8]) __attribute__((always_inline)) {
-      const float* ar = As + st * A_STAGE + wr * MT * 32 + li;
+    // this chunk's A fragments, split: from fp32 k-rows (read + split here) or, APRE, three b128 reads of the bf16 planes
+    auto load_a = [&](int st, Split8 (&fa)[MT]) __attribute__((always_inline)) {
+      if constexpr (APRE) {
+        const u32x4* ap = reinterpret_cast<const u32x4*>(As + st * A_STAGE) + lh * ROWS + wr * MT * 32 + li;
 #pragma unroll
-      for (int t = 0; t < MT; ++t)
+        for (int t = 0; t < MT; ++t) {
+          fa[t].h = ap[t * 32];
+          fa[t].m = ap[2 * ROWS + t * 32];
+          fa[t].l = ap[4 * ROWS + t * 32];
+        }
+      } else {
+        const float* ar = As + st * A_STAGE + wr * MT * 32 + li;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ra[t][j] = ar[(2 * j + lh) * ROWS + t * 32];
+        for (int t = 0; t < MT; ++t) {
+          float ra[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ra[j] = ar[(2 * j + lh) * ROWS + t * 32];
+          split8(ra, fa[t]);
+        }
+      }
     };
     auto read_col = [&](int st, int u, float (&x)[8]) __attribute__((always_inline)) {
       const float* bs = Bs + st * B_STAGE + wc * CW + NTC * li + u;
@@ -956,11 +982,8 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && MT * (CW / 32) >= 6) ?
     Split8 fa0[MT], fa1[MT], fb[2];
     float rc[8];   // raw column in flight
     if (nchunks > 0) {
-      float ra[MT][8];
-      read_a(0, ra);
+      load_a(0, fa0);
       read_col(0, 0, rc);
-#pragma unroll
-      for (int t = 0; t < MT; ++t) split8(ra[t], fa0[t]);
       split8(rc, fb[0]);
       read_col(0, 1 % NTC, rc);
     }
@@ -982,18 +1005,15 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && MT * (CW / 32) >= 6) ?
       __builtin_amdgcn_sched_barrier(0);
       stage = stage == ST - 1 ? 0 : stage + 1;
       __syncthreads();   // every consumer has read this chunk out of LDS; the producer has the next one landed
-      float ra[MT][8];
-      read_a(stage, ra);
+      load_a(stage, fan);
       read_col(stage, 0, rc);
-#pragma unroll
-      for (int t = 0; t < MT; ++t) split8(ra[t], fan[t]);
       split8(rc, fb[NTC & 1]);
 #pragma unroll
       for (int t = 0; t < MT; ++t) acc[t][NTC - 1] = split_mac(fa[t], fb[(NTC - 1) & 1], acc[t][NTC - 1]);
 #pragma unroll
       for (int i = 0; i < 6 * MT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, (44 * (MT + 1) + 6 * MT - 1) / (6 * MT), 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (44 * (APRE ? 1 : MT + 1) + 6 * MT - 1) / (6 * MT), 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       read_col(stage, 1 % NTC, rc);
@@ -1136,6 +1156,27 @@ __global__ void filter_tapmajor_kernel(const float* __restrict__ W, float* __res
     const int tap = r % TYX;
     const int c = (int)(r / TYX) * 16 + c16;
     Wt[i] = W[(size_t)f + (size_t)F * (tap + (size_t)TYX * c)];
+  }
+}
+
+// A operand of ggp_kernel<…, SPLIT, APRE>: the re-laid fp32 bank Wt[(16*chunk + krow)*R + row] becomes bf16 planes
+// out[(((chunk*3 + plane)*2 + lh)*R + row)*8 + j] = plane(h/m/l) of Wt[(16*chunk + 2j + lh)*R + row]  (exact split, Split8).
+__global__ void split_planes_kernel(const float* __restrict__ Wt, u32x4* __restrict__ out, int chunks, int R) {
+  const size_t total = (size_t)chunks * 2 * R;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i % R);
+    const size_t r = i / R;
+    const int lh = (int)(r & 1);
+    const size_t chunk = r >> 1;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = Wt[(chunk * 16 + 2 * j + lh) * (size_t)R + row];
+    Split8 sp;
+    split8(x, sp);
+    u32x4* o = out + ((chunk * 3) * 2 + lh) * (size_t)R + row;
+    o[0] = sp.h;
+    o[2 * (size_t)R] = sp.m;
+    o[4 * (size_t)R] = sp.l;
   }
 }
 
@@ -1634,7 +1675,11 @@ void gg_launch_classes(GGParams& p, GGClassTable& ct, bool vec) {
     CHIP_REQUIRE(vec && WC * (CW / 4) == 64);
     if constexpr (WC * (CW / 4) == 64) {
       const size_t lds3 = lds / 2 * 3;
-      if (gg_split_mode()) {
+      if (gg_split_mode() && p.apre) {
+        const size_t lds3p = sizeof(float) * 3 * (6 * ROWS * 4 + B_STAGE);
+        allow_big_lds(ggp_kernel<WR, WC, MT, CW, true, true>, lds3p);
+        hipLaunchKernelGGL((ggp_kernel<WR, WC, MT, CW, true, true>), grid, dim3(WR * WC * 64 + 64), lds3p, stream(), p, ct);
+      } else if (gg_split_mode()) {
         allow_big_lds(ggp_kernel<WR, WC, MT, CW, true>, lds3);
         hipLaunchKernelGGL((ggp_kernel<WR, WC, MT, CW, true>), grid, dim3(WR * WC * 64 + 64), lds3, stream(), p, ct);
       } else {
@@ -1678,8 +1723,9 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   if constexpr (!AK && WC * (CW / 4) == 64) {
     if (p.KC > 0) {
       static const int pslots_s = resident_slots(ggp_kernel<WR, WC, MT, CW, true>, WR * WC * 64 + 64, sizeof(float) * 3 * (A_STAGE + B_STAGE));
+      static const int pslots_p = resident_slots(ggp_kernel<WR, WC, MT, CW, true, true>, WR * WC * 64 + 64, sizeof(float) * 3 * (6 * ROWS * 4 + B_STAGE));
       static const int pslots_f = resident_slots(ggp_kernel<WR, WC, MT, CW>, WR * WC * 64 + 64, sizeof(float) * 3 * (A_STAGE + B_STAGE));
-      slots_launch = gg_split_mode() ? pslots_s : pslots_f;
+      slots_launch = gg_split_mode() ? (p.apre ? pslots_p : pslots_s) : pslots_f;
     }
   }
   // FLOP/s of one resident block, for the two estimates below: fp32 MFMA = half a CU (64 FLOP/clk/SIMD, 2 blocks per CU) at 80 %;
@@ -1760,7 +1806,11 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
     if constexpr (!AK && WC * (CW / 4) == 64) {
       if (p.KC > 0) {
         const size_t lds3 = sizeof(float) * 3 * (A_STAGE + B_STAGE) + lds_pad;
-        if (gg_split_mode()) {
+        if (gg_split_mode() && p.apre) {
+          const size_t lds3p = sizeof(float) * 3 * (6 * ROWS * 4 + B_STAGE) + lds_pad;
+          allow_big_lds(ggp_kernel<WR, WC, MT, CW, true, true>, lds3p);
+          hipLaunchKernelGGL((ggp_kernel<WR, WC, MT, CW, true, true>), grid, dim3(WR * WC * 64 + 64), lds3p, stream(), p, kNoClasses);
+        } else if (gg_split_mode()) {
           allow_big_lds(ggp_kernel<WR, WC, MT, CW, true>, lds3);
           hipLaunchKernelGGL((ggp_kernel<WR, WC, MT, CW, true>), grid, dim3(WR * WC * 64 + 64), lds3, stream(), p, kNoClasses);
         } else {
@@ -1938,6 +1988,21 @@ ConvGeo conv_geo(const Shape4D* img, const Shape4D* flt, const Shape4D* out, con
   return g;
 }
 
+// bf16-plane image of a re-laid bank of `elems` floats with R rows per k-row (split_planes_kernel); `out` holds 1.5 x elems floats
+inline bool gg_presplit_mode() {
+  static const bool off = getenv("CONVNET_GG_NO_PRESPLIT") != nullptr;
+  return gg_split_mode() && !off;
+}
+void presplit_bank(const float* bank, float* out, size_t elems, int R, const char* op) {
+  const int chunks = (int)(elems / ((size_t)16 * R));
+  CHIP_REQUIRE((size_t)chunks * 16 * R == elems);
+  const size_t work = (size_t)chunks * 2 * R;
+  int nb = (int)((work + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  KernelTimer timer("split_planes_kernel", op, 0.0, 10.0 * elems);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(nb), dim3(256), 0, stream(), bank, reinterpret_cast<u32x4*>(out), chunks, R);
+}
+
 void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* targets, Shape4D* is, Shape4D* fs, Shape4D* ts,
                   const ConvDesc& d, float scaleTargets, int relu) {
   const ConvGeo g = conv_geo(is, fs, ts, d, images, filters, targets);
@@ -1953,14 +2018,20 @@ void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* tar
   const bool vec = g.N % 4 == 0 && g.F % 4 == 0 && aligned16(p.A) && aligned16(p.src) && aligned16(p.dst);
   if (vec && ggp_shape_ok(g.F, g.C)) {
     // producer-wave kernel: the reduction runs tap-major over a re-laid copy of the filter bank (a few MB, ~5 us)
+    const size_t welems = (size_t)g.F * p.K;
+    const bool pre = gg_presplit_mode();
+    float* wt = (p.TYX > 1 || pre) ? static_cast<float*>(workspace_aux(sizeof(float) * (welems + (pre ? welems + welems / 2 : 0)))) : nullptr;
     if (p.TYX > 1) {
-      const size_t welems = (size_t)g.F * p.K;
-      float* wt = static_cast<float*>(workspace_aux(sizeof(float) * welems));
       int nb = (int)((welems + 255) / 256);
       if (nb > 2048) nb = 2048;
       KernelTimer timer("filter_tapmajor_kernel", "conv_fprop", 0.0, 8.0 * welems);
       hipLaunchKernelGGL(filter_tapmajor_kernel, dim3(nb), dim3(256), 0, stream(), filters->data_device, wt, g.F, g.C, p.TYX);
       p.A = wt;
+    }
+    if (pre) {   // the consumers read the bank as ready-made bf16 planes
+      presplit_bank(p.A, wt + welems, welems, g.F, "conv_fprop");
+      p.A = wt + welems;
+      p.apre = 1;
     }
     p.KC = g.C;
   }
@@ -2006,7 +2077,8 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
   if (mask) CHIP_REQUIRE(numel(mask) == numel(targets));
   // one launch per stride class (cy,cx): input rows iy with (iy - pad) % sy == cy share the tap set
   // ky = cy + sy*a; their sources are oy = (iy - pad - cy)/sy - a  (pad = ConvDesc padding, <= 0).
-  float* wt = static_cast<float*>(workspace_aux(sizeof(float) * (size_t)g.C * g.F * g.Ky * g.Kx + 256 * g.sy * g.sx));
+  const size_t wt_floats = ((size_t)g.C * g.F * g.Ky * g.Kx + 64 * (size_t)g.sy * g.sx + 63) / 64 * 64;
+  float* wt = static_cast<float*>(workspace_aux(sizeof(float) * (wt_floats + wt_floats + wt_floats / 2)));   // + room for the bf16 planes
   size_t woff = 0;
   double flops = 0;
   int blocks = 0;
@@ -2021,6 +2093,9 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
   GGClassTable ct{};
   const bool tapm = vec && ggp_shape_ok(g.C, g.F);   // producer-wave kernel: k = tap*F + f over tap-major class filters
   if (tapm) base.KC = g.F;
+  const bool pre = tapm && gg_presplit_mode();        // ... reading the class banks as bf16 planes (split_planes_kernel)
+  float* const planes = wt + wt_floats;
+  if (pre) base.apre = 1;
   const bool multi = g.sy * g.sx > 1 && g.sy * g.sx <= kMaxClasses;   // all classes in one launch (no wave-quantisation per class)
   t_op = "conv_dgrad";
   // Work accounting.  ALGORITHMIC = the transposed convolution's MACs, 2*N*My*Mx*F*C*Ky*Kx (every output pixel meets every tap
@@ -2063,6 +2138,11 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
       }
       GGClass k{};
       k.A = wc; k.K = g.F * TYc * TXc;
+      if (pre && welems > 0) {
+        float* pc = planes + (size_t)(wc - wt) / 2 * 3;
+        presplit_bank(wc, pc, welems, g.C, "conv_dgrad");
+        k.A = pc;
+      }
       k.GX = GX; k.G = GY * GX; k.TX = TXc > 0 ? TXc : 1; k.TYX = TYc * TXc > 0 ? TYc * TXc : 1;
       k.y0 = jy0; k.x0 = jx0; k.dy0 = iy0; k.dx0 = ix0;
       const double cflops = 2.0 * g.N * k.G * (double)g.C * k.K;
