@@ -61,8 +61,8 @@ def _same_kernel(bench_name, prof_name):
         return False
     rest = fa[len(nums):]
     split = "split" in wa
-    if wb == "ggp_kernel":       # <WR, WC, MT, CW, SPLIT>
-        return (rest[:1] == ["true"]) == split
+    if wb == "ggp_kernel":       # <WR, WC, MT, CW, SPLIT, APRE>
+        return (rest[:1] == ["true"]) == split and ((len(rest) > 1 and rest[1] == "true") == ("pre" in wa))
     if wb == "wg_kernel":        # <WM, WN, MT, NTL, VEC, TS, SPLIT>
         return len(rest) >= 2 and (rest[1] == "16") == ("x16" in wa) and ((len(rest) > 2 and rest[2] == "true") == split)
     if wb == "gg_kernel":        # <WR, WC, MT, CW, A_KCONTIG, VEC, O3, SPLIT>
@@ -192,8 +192,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--model", default="alexnet", choices=["alexnet", "alexnet_nin", "mnist_conv", "lenet5", "vgg"])
-    ap.add_argument("--side-stream-update", action="store_true",
-                    help="enqueue each edge's optimizer step on a second stream during Bprop (measured: no gain on 1 GPU)")
+    ap.add_argument("--no-side-stream-update", action="store_true",
+                    help="serial UpdateWeights after Bprop instead of each edge's optimizer step on the second stream as soon as its "
+                         "gradient is final (bit-identical either way; measured with --overlap-wgrad: 11.23 -> 11.08 ms/step)")
+    ap.add_argument("--no-overlap-wgrad", action="store_true",
+                    help="every edge's weight gradient on the main stream instead of on a second stream beside the rest of the backward "
+                         "pass (bit-identical either way; measured 11.47 -> 11.23 ms/step)")
     ap.add_argument("--timer-every", type=int, default=4, help="steps between kernel-timer (HIP event) sampled steps")
     ap.add_argument("--no-kernel-timers", action="store_true", help="diagnostic: no per-launch HIP events (roofline fields empty)")
     ap.add_argument("--staged-input", action="store_true", help="GPU-resident 256x256 chunk + crop/flip/transpose staging per batch instead of pre-staged batches")
@@ -252,7 +256,7 @@ def main():
 
     text = getattr(models, args.model)()
     net = ConvNet(text, fused=not args.unfused, process_id=rank, num_processes=world, exchange=exchange,
-                  overlap_update=args.side_stream_update)
+                  overlap_update=not args.no_side_stream_update, overlap_wgrad=not args.no_overlap_wgrad)
     net.SetBatchsize(args.batch)
     if args.staged_input:
         # the reference's real input path: a GPU-resident chunk of 256x256 images, per-batch random 224 crop + flip +
@@ -355,7 +359,7 @@ def main():
                              "achieved": round(SPLIT_PRODUCTS * (executed if executed > 0 else achieved), 1), "peak": PEAK_BF16_MATRIX_TFLOPS,
                              "unit": "TFLOP/s (bf16, executed)",
                              "frac": round(SPLIT_PRODUCTS * (executed if executed > 0 else achieved) / PEAK_BF16_MATRIX_TFLOPS, 4)}}
-                   if dom_name.endswith(",split>") else {}),
+                   if ",split" in dom_name else {}),
                 "families": {k: {"launches_per_step": v["launches"] / timed_steps, "ms_per_step": round(v["ms"] / timed_steps, 4),
                                  **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                      "executed_tflops": round(v["executed"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] > 0 else
@@ -379,6 +383,8 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" + ("" if world == 1 else (" rccl-allreduce " + ("overlapped" if not args.no_overlap else "serial") + (" (C-ABI entries)" if args.transport == "abi" else "")))
                                       + (f" strong (global batch {args.global_batch} = {args.batch}/GPU)" if strong else f" weak ({args.batch}/GPU)"),
+                       "streams": ("weight gradients" if not args.no_overlap_wgrad else "") + (" + optimizer steps" if not args.no_side_stream_update else "") +
+                                  (" on a second HIP stream beside the backward pass" if not (args.no_overlap_wgrad and args.no_side_stream_update) else "one stream"),
                        "params": net.NumParameters(), "train_gflop_per_image": round(2e-9 * train_macs, 4)},
             "roofline": roofline,
         }

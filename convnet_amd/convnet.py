@@ -28,16 +28,22 @@ from .trainer import TrainLoopMixin
 
 
 class ConvNet(TrainLoopMixin):
-    def __init__(self, model, fused=False, process_id=0, num_processes=1, verbose=False, exchange=None, overlap_update=None):
+    def __init__(self, model, fused=False, process_id=0, num_processes=1, verbose=False, exchange=None, overlap_update=None,
+                 overlap_wgrad=None):
         """``model``: path to a pbtxt file, pbtxt text, or a parsed pbtxt.Model.
         ``overlap_update`` (default off): inside TrainOneBatch each edge's optimizer step is enqueued on a second
         HIP stream as soon as that edge's wgrad + dgrad (and, data-parallel, its gradient bucket's all-reduce)
         are done.  Same arithmetic as the reference's serial UpdateWeights (bit-identical, tested).  Measured on
         one MI355X it is throughput-neutral (18.34 vs 18.36 ms/step): the co-running HBM-bound update kernels take
-        CU slots from the MFMA kernels and slow them by what they save, so it stays opt-in."""
+        CU slots from the MFMA kernels and slow them by what they save, so it stays opt-in.
+        ``overlap_wgrad`` (default off): inside TrainOneBatch every edge's ComputeOuter (weight gradient, matrix-pipe bound) is
+        enqueued on the second stream, ordered after the derivative it reads; the main stream goes straight on to the edge's
+        ComputeDown and the next layers' backward (pool / response-norm undo are HBM-bound and can share the chip with it).
+        The optimizer step (on either stream) and the gradient exchange are ordered behind it.  Same arithmetic."""
         self.verbose = verbose
         self.fused = fused
         self.overlap_update_ = bool(overlap_update)
+        self.overlap_wgrad_ = bool(overlap_wgrad)
         self.side_stream_ = None
         self._pending_updates = []     # [(edge, event on the main stream after its dgrad, held back?)]
         self._in_train_step = False
@@ -249,21 +255,33 @@ class ConvNet(TrainLoopMixin):
             now.record(torch.cuda.current_stream())
             self._pending_updates = [(e, now, False) for e, _, _ in self._pending_updates]
             self._flush_updates(final=False)
-        edge.ComputeOuter(input.GetState(), output.GetDeriv())
         # The gradient slice belongs to the OWNER of the weights: an edge tied to another one (tied_to) accumulates into its
         # owner's slice (edge_with_weight.cc:66-90), so the slice is final only when the last sharing edge has added its part —
         # whichever of them comes last in backward order.
         owner = edge.tied_edge_ if edge.IsTied() else edge
-        complete = isinstance(owner, EdgeWithWeight) and owner.GetNumGradsReceived() >= owner.num_shares_
-        if self.exchange_ is not None and owner in self.edge_slices_ and complete:
-            self.exchange_.GradReady(owner)     # the slice is final: start its all-reduce
+        if side and self.overlap_wgrad_ and isinstance(edge, EdgeWithWeight):
+            # weight gradient on the second stream, behind everything enqueued so far (the derivative it reads); the all-reduce of
+            # a completed slice is posted from that stream too, so its `ready` event covers the wgrad
+            here = torch.cuda.Event()
+            here.record(torch.cuda.current_stream())
+            self.side_stream_.wait_event(here)
+            with Matrix.OnStream(self.side_stream_):
+                edge.ComputeOuter(input.GetState(), output.GetDeriv())
+                complete = isinstance(owner, EdgeWithWeight) and owner.GetNumGradsReceived() >= owner.num_shares_
+                if self.exchange_ is not None and owner in self.edge_slices_ and complete:
+                    self.exchange_.GradReady(owner)
+        else:
+            edge.ComputeOuter(input.GetState(), output.GetDeriv())
+            complete = isinstance(owner, EdgeWithWeight) and owner.GetNumGradsReceived() >= owner.num_shares_
+            if self.exchange_ is not None and owner in self.edge_slices_ and complete:
+                self.exchange_.GradReady(owner)     # the slice is final: start its all-reduce
         if not input.IsInput():
             overwrite = input.AddOrOverwriteDeriv(edge.GetSourceSliceName())
             if fuse_mask is not None:
                 edge.ComputeDown(output.GetDeriv(), input.GetState(), output.GetState(), input.GetDeriv(), overwrite, fuse_mask=fuse_mask)
             else:
                 edge.ComputeDown(output.GetDeriv(), input.GetState(), output.GetState(), input.GetDeriv(), overwrite)
-        if side and isinstance(owner, EdgeWithWeight) and complete:
+        if side and self.overlap_update_ and isinstance(owner, EdgeWithWeight) and complete:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())   # wgrad AND dgrad (which reads the weights) are enqueued
             # An FC edge's backward at batch <= a few hundred is itself HBM-bound (it streams the weight matrix
@@ -362,13 +380,15 @@ class ConvNet(TrainLoopMixin):
     # ---- update: src/convnet.cc:440-450 -------------------------------------------------------------------
     def UpdateWeights(self):
         if self._in_train_step and self.side_stream_ is not None:
-            # every edge went through _bprop_edge: drain what is still waiting for its bucket, then make the
-            # main stream (next Fprop reads the weights) wait for the side stream
-            self._flush_updates(final=True)
+            if self.overlap_update_:
+                # every edge went through _bprop_edge: drain what is still waiting for its bucket, then make the
+                # main stream (next Fprop reads the weights) wait for the side stream
+                self._flush_updates(final=True)
             done = torch.cuda.Event()
             done.record(self.side_stream_)
-            torch.cuda.current_stream().wait_event(done)
-            return
+            torch.cuda.current_stream().wait_event(done)   # weight gradients (and side-stream updates) are in
+            if self.overlap_update_:
+                return
         for e in self.edges_:
             if e.IsBackPropBlocked():
                 continue
@@ -394,7 +414,7 @@ class ConvNet(TrainLoopMixin):
             l.NotifyStart()
         if self.exchange_ is not None:
             self.exchange_.StartStep()
-        if self.overlap_update_ and self.side_stream_ is None and torch.cuda.is_available():
+        if (self.overlap_update_ or self.overlap_wgrad_) and self.side_stream_ is None and torch.cuda.is_available():
             self.side_stream_ = torch.cuda.Stream()
         self.GetBatch(self.train_dataset_)
         self.Fprop(True)

@@ -1666,7 +1666,9 @@ void gg_launch_classes(GGParams& p, GGClassTable& ct, bool vec) {
   }
   static const std::string kname_g = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ",rc>";
   static const std::string kname_p = "ggp_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ">";
-  static const std::string kname_s = kname_p.substr(0, kname_p.size() - 1) + ",split>";
+  static const std::string kname_s0 = kname_p.substr(0, kname_p.size() - 1) + ",split>";
+  static const std::string kname_s1 = kname_p.substr(0, kname_p.size() - 1) + ",split,pre>";   // A read as pre-split bf16 planes
+  const std::string& kname_s = p.apre ? kname_s1 : kname_s0;
   static const std::string kname_gs = kname_g.substr(0, kname_g.size() - 1) + ",split>";
   const std::string& kname = p.KC > 0 ? (gg_split_mode() ? kname_s : kname_p) : ((vec && gg_split_mode()) ? kname_gs : kname_g);
   KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, (p.KC > 0 && p.nblk % WC == 0) ? 0.0 : t_exec);
@@ -1788,7 +1790,9 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   dim3 block(WR * WC * 64);
   static const std::string kname_g = "gg_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + "," + (AK ? "kc" : "rc") + ">";
   static const std::string kname_p = "ggp_kernel<" + std::to_string(WR) + "," + std::to_string(WC) + "," + std::to_string(MT) + "," + std::to_string(CW) + ">";
-  static const std::string kname_s = kname_p.substr(0, kname_p.size() - 1) + ",split>";
+  static const std::string kname_s0 = kname_p.substr(0, kname_p.size() - 1) + ",split>";
+  static const std::string kname_s1 = kname_p.substr(0, kname_p.size() - 1) + ",split,pre>";   // A read as pre-split bf16 planes
+  const std::string& kname_s = p.apre ? kname_s1 : kname_s0;
   static const std::string kname_gs = kname_g.substr(0, kname_g.size() - 1) + ",split>";
   const std::string& kname = p.KC > 0 ? (gg_split_mode() ? kname_s : kname_p) : ((vec && gg_split_mode()) ? kname_gs : kname_g);
   {

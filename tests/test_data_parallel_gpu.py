@@ -184,7 +184,7 @@ def nccl_one_rank():
 
 
 @pytest.mark.parametrize("transport", ["torch", "abi"])
-@pytest.mark.parametrize("which,side", [("tiny_alex", False), ("dag", True), ("tied", True)])
+@pytest.mark.parametrize("which,side", [("tiny_alex", False), ("dag", True), ("tied", True), ("tiny_alex", "wgrad"), ("tied", "wgrad"), ("dag", "both")])
 def test_one_rank_rccl_overlap_path_is_bit_identical_to_no_exchange(nccl_one_rank, transport, which, side):
     """Events, communication stream, bucket ranges (several per bucket on the DAG) and the per-edge waits, with a world of one:
     the all-reduce is the identity, so any difference from the plain run is a synchronisation or range bug."""
@@ -196,7 +196,8 @@ def test_one_rank_rccl_overlap_path_is_bit_identical_to_no_exchange(nccl_one_ran
     runs = []
     for ex in (None, "x"):
         exchange = GradientExchange(bucket_bytes=2048, overlap=True, transport=transport) if ex else None
-        net = ConvNet(net_text(which), fused=True, exchange=exchange, overlap_update=side and ex is not None)
+        net = ConvNet(net_text(which), fused=True, exchange=exchange, overlap_update=side in (True, "both") and ex is not None,
+                      overlap_wgrad=side in ("wgrad", "both") and ex is not None)   # "wgrad": weight gradients (and their all-reduce posts) on the second stream
         net.SetBatchsize(B)
         net.SetupDataset(SliceData(net, B, 0, 1, seed=9, num_batches=2))
         net.AllocateMemory(False)

@@ -229,15 +229,17 @@ def test_training_fits_a_fixed_batch_and_dropout_net_stays_finite(gpu):
 
 
 @pytest.mark.gpu
-def test_side_stream_updates_are_bit_identical_to_serial_updates(gpu):
-    """overlap_update enqueues each edge's optimizer step on a second stream during Bprop; weights, momentum
-    history and gradients after several steps must equal the serial UpdateWeights run bit for bit (dropout off:
+@pytest.mark.parametrize("mode", ["update", "wgrad", "both"])
+def test_side_stream_updates_are_bit_identical_to_serial_updates(gpu, mode):
+    """overlap_update enqueues each edge's optimizer step on a second stream during Bprop, overlap_wgrad each edge's weight
+    gradient; weights, momentum history and gradients after several steps must equal the serial run bit for bit (dropout off:
     the RNG stream is shared state)."""
     from convnet_amd.convnet import ConvNet
     from convnet_amd.datahandler import SyntheticDataHandler
     nets = []
     for overlap in (False, True):
-        net = ConvNet(small_alexnet(dropprob=0.0), fused=True, overlap_update=overlap)
+        net = ConvNet(small_alexnet(dropprob=0.0), fused=True, overlap_update=overlap and mode in ("update", "both"),
+                      overlap_wgrad=overlap and mode in ("wgrad", "both"))
         net.SetBatchsize(32)
         net.SetupDataset(SyntheticDataHandler(net, 32, seed=11, num_batches=2))
         net.AllocateMemory(False)
