@@ -22,6 +22,8 @@ Extra objects on the line:
                 operand splits (six bf16 MFMAs per 32x32x16 block; include/convnet_hip.h), so `frac` can
                 exceed 1; `roofline.pipe` prices the same launches against the pipe they execute on
                 (6 executed bf16 flops per algorithmic flop, 2.5 PFLOP/s dense bf16 peak).
+                With the second stream on (default) a launch's duration includes what the co-running kernel of the
+                other stream took — `roofline.one_stream` gives the dominant kernel's rate without a neighbour.
   fp32_mfma_path  the same step with every GEMM kernel on v_mfma_f32_32x32x2_f32 instead (--matrix-path fp32),
                 timed in this process right after the main run (rank 0, N=1 only): the number to read if the
                 bf16-split products are not accepted as fp32 arithmetic.
@@ -90,6 +92,17 @@ def pmc_traffic(kernel, args):
                         "traffic_source": "NOT measured in this run (PMC needs rocprofv3 around the process): read from the committed "
                                           "passes of this same command, " + os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))}
     return {"traffic": None}
+
+
+def one_stream_fields(rows, kernel):
+    """`roofline.one_stream`: the dominant kernel's rate in the extra one-stream steps (no co-running kernel)."""
+    rows = [r for r in (rows or []) if r["kernel"] == kernel]
+    ms, flops, n = sum(r["ms"] for r in rows), sum(r["flops"] for r in rows), sum(r["launches"] for r in rows)
+    if not rows or ms <= 0:
+        return {}
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"one_stream": {"achieved": round(tf, 2), "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4), "avg_launch_ms": round(ms / n, 4), "launches": n,
+                           "note": "the same kernel in 4 extra steps with everything on one stream (no co-running kernel), after the timed region"}}
 
 
 def cpu_baseline(sample_n=6):   # ~13 s of CPU work on the 256-core GPU box (N=2 took 4.1-4.7 s; the cost is linear in N)
@@ -307,6 +320,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    # With the weight gradients / optimizer steps on a second stream, kernels of the two streams share the chip, so a launch's
+    # event (and rocprofv3) duration includes what its neighbour took.  Four more steps on ONE stream, every launch timed, give the
+    # dominant kernel's undisturbed rate beside the one measured in the timed region (every rank runs them: collectives inside).
+    prof_one_stream = None
+    if not (args.no_overlap_wgrad and args.no_side_stream_update) and not args.no_kernel_timers:
+        keep = (net.overlap_wgrad_, net.overlap_update_)
+        net.overlap_wgrad_, net.overlap_update_ = False, False
+        net.TrainOneBatch()
+        sync_all()
+        _lib.profile_enable(True)
+        for _ in range(4):
+            net.TrainOneBatch()
+        sync_all()
+        _lib.profile_enable(False)
+        prof_one_stream = _lib.profile_report()
+        net.overlap_wgrad_, net.overlap_update_ = keep
+
     other = None
     if world == 1 and not args.no_other_path:
         # the same step on the other matrix path, same process, same net: 3 warm-up steps, then the same number of timed steps
@@ -360,6 +390,7 @@ def main():
                              "unit": "TFLOP/s (bf16, executed)",
                              "frac": round(SPLIT_PRODUCTS * (executed if executed > 0 else achieved) / PEAK_BF16_MATRIX_TFLOPS, 4)}}
                    if ",split" in dom_name else {}),
+                **one_stream_fields(prof_one_stream, dom_name),
                 "families": {k: {"launches_per_step": v["launches"] / timed_steps, "ms_per_step": round(v["ms"] / timed_steps, 4),
                                  **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                      "executed_tflops": round(v["executed"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] > 0 else
