@@ -63,6 +63,8 @@ struct GGParams {
   int lda;            // A[r + lda*k] (r-contiguous) or A[k + lda*r] (k-contiguous)
   int GX, G;          // output pixel grid of this launch: G = GY*GX pixels, m = oy*GX + ox
   int TX, TYX;        // taps: k = ch*TYX + a*TX + b   (channel-major, KC == 0)
+  int ablate;         // ggp_kernel timing diagnostic (CONVNET_GG_ABLATE; results are WRONG): 1 = every staging load reads the zero page
+                      // (address work and LDS-DMA issue kept, no memory traffic), 2 = no staging after the second chunk
   int apre;           // ggp_kernel split build: A is the pre-split bf16-plane image of the bank (split_planes_kernel)
   int KC;             // > 0 (ggp_kernel): reduction order k = ((cb*TYX + tap)*BK + c16, channel ch = cb*BK + c16 of KC — every chunk of BK
                       // k-rows is ONE tap of one 16-channel block, taps innermost — over a filter bank re-laid to match
@@ -857,7 +859,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
     }
     const float* const zero = p.zero;
     const float* const src = p.src;
-    const int dir = p.dir, SH = p.SH, SW = p.SW, lda = p.lda, R = p.R;
+    const int dir = p.dir, SH = p.SH, SW = p.SW, lda = p.lda, R = p.R, ablate = p.ablate;
     const unsigned plane_bytes = (unsigned)SH * (unsigned)SW * (unsigned)N * 4u;   // < 2^31 floats per tensor (conv_geo)
     const float* bptr;        // this lane's element of k-row 0 of the next chunk to issue
     unsigned bstride;         // bytes between consecutive k-rows for this lane (0 on the zero page)
@@ -892,14 +894,15 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
       const char* const abase = abase0 + a_chunk_bytes * (size_t)(cb * TYX + ta * TX + tb);   // wave-uniform
 #pragma unroll
       for (int it = 0; it < NA; ++it) {
-        const float* ap = a_ok[it] ? reinterpret_cast<const float*>(abase + a_off[it]) : zero;
+        const float* ap = (a_ok[it] && ablate != 1) ? reinterpret_cast<const float*>(abase + a_off[it]) : zero;
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)ap, (lds_ptr_t)(As + stage * A_STAGE + 4 * 64 * it), 16, 0, 0);
       }
-      const char* bp = reinterpret_cast<const char*>(bptr);
+      const char* bp = reinterpret_cast<const char*>(ablate == 1 ? zero : bptr);
+      const unsigned bstep = ablate == 1 ? 0u : bstride;
 #pragma unroll
       for (int it = 0; it < NB; ++it) {
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)bp, (lds_ptr_t)(Bs + stage * B_STAGE + 4 * 64 * it), 16, 0, 0);
-        bp += bstride;
+        bp += bstep;
       }
       // next chunk: the next tap of the rectangle for the same 16 channels, then the next channel block.  Taps innermost keeps
       // what neighbouring tiles fetch for tap t+1 one chunk — not one whole tap run — away from what they fetched for tap t.
@@ -921,7 +924,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
     __builtin_amdgcn_s_barrier();
     int fill = 2;   // stage of chunk c + 2
     for (int c = 0; c < nchunks; ++c) {
-      const bool more2 = c + 2 < nchunks;
+      const bool more2 = c + 2 < nchunks && ablate != 2;
       if (more2) issue(fill);
       fill = fill == ST - 1 ? 0 : fill + 1;
       // chunk c+1 must have landed before the consumers are released into it
@@ -1598,6 +1601,10 @@ inline int gg_prio_mode() {
 
 // The producer-wave build of the gather-GEMM (ggp_kernel) for the launches that have one (r-contiguous A, vector path,
 // 64 pieces per k-row).  On by default; CONVNET_GG_PRODUCER=0 restores gg_kernel everywhere (A/B runs).
+inline int gg_ablate_mode() {
+  static const int v = [] { const char* e = getenv("CONVNET_GG_ABLATE"); return e && *e ? atoi(e) : 0; }();
+  return v;
+}
 inline bool gg_producer_mode() {
   static const bool v = [] { const char* e = getenv("CONVNET_GG_PRODUCER"); return e && *e ? atoi(e) != 0 : true; }();
   return v;
@@ -1652,6 +1659,7 @@ void gg_launch_classes(GGParams& p, GGClassTable& ct, bool vec) {
   p.row_tiles = divup(p.R, ROWS);
   p.zero = zero_page();
   p.prio = gg_prio_mode();
+  p.ablate = gg_ablate_mode();
   p.splits = 1;
   p.chunks_per_split = 1 << 24;
   p.partial = nullptr;
@@ -1715,6 +1723,7 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   p.col_tiles = divup(p.ncols, WC);
   p.zero = zero_page();
   p.prio = gg_prio_mode();
+  p.ablate = gg_ablate_mode();
   const int tiles = p.row_tiles * p.col_tiles;
   const int kchunks = divup(p.K, BK);
   // 3 blocks per CU (768 slots) for launches with at least two such rounds of tiles; only the 128-row r-contiguous
