@@ -137,11 +137,12 @@ def test_check_reduce_learning_rate_follows_the_reference_rule():
     assert not net.CheckReduceLearningRate([0.6, 0.6, 0.5, 0.5])                  # an error metric that still falls
 
 
-def test_committed_bench_line_follows_the_driver_contract():
-    """profiles/r01_bench_n1.json is the line `python bench.py` printed on the MI355X: every field the driver and the
+@pytest.mark.parametrize("which", ["r01_bench_n1.json", "r02_bench_n1.json", "r02_fp32path_bench_n1.json"])
+def test_committed_bench_line_follows_the_driver_contract(which):
+    """profiles/rNN_bench_n1.json is the line `python bench.py` printed on the MI355X: every field the driver and the
     judge read is present, typed, and self-consistent."""
     import json
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_bench_n1.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", which)
     d = json.load(open(path))
     for k, t in [("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                  ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict),
@@ -156,6 +157,13 @@ def test_committed_bench_line_follows_the_driver_contract():
     assert r["achieved"] == pytest.approx(r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12, rel=2e-2)
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == "images/sec" and c["sample"]
+    if which == "r02_bench_n1.json":
+        # the default matrix path forms fp32 products on the bf16 pipe: the line carries the fp32-instruction run beside it, the
+        # pipe-level accounting, and the dominant kernel's rate without a co-running kernel of the second stream
+        assert "bf16" in d["arithmetic"] and d["fp32_mfma_path"]["matrix_path"] == "fp32" and d["fp32_mfma_path"]["value"] < d["value"]
+        assert r["pipe"]["peak"] == 2500.0 and r["pipe"]["executed_per_algorithmic_flop"] == 6
+        assert r["one_stream"]["achieved"] > r["achieved"] and r["traffic"] > 0 and r["kernel"].endswith(",split,pre>")
+        assert d["ref_host"]["value"] > 0
 
 
 def test_nin_model_graph_and_work_count():
@@ -237,3 +245,29 @@ def test_pbtxt_schema_matches_the_reference_proto_field_for_field():
                 assert abs(float(mine) - want) <= 1e-9 * max(1.0, abs(want)), (name, key, mine, want)
             else:
                 assert mine == want and type(mine) is type(want), (name, key, mine, want)
+
+
+def test_bench_kernel_name_matching_and_one_stream_fields():
+    """bench.py pairs its kernel-family names with rocprofv3's full template argument lists (roofline.traffic lookup) and derives the
+    dominant kernel's one-stream rate from the library's per-launch profile rows."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    same = b._same_kernel
+    assert same("ggp_kernel<2,2,2,128,split,pre>", "void chip::ggp_kernel<2, 2, 2, 128, true, true>(chip::GGParams, chip::GGClassTable)")
+    assert same("ggp_kernel<2,2,2,128,split>", "ggp_kernel<2, 2, 2, 128, true, false>")
+    assert not same("ggp_kernel<2,2,2,128,split>", "ggp_kernel<2, 2, 2, 128, true, true>")
+    assert same("ggp_kernel<2,2,2,128>", "ggp_kernel<2, 2, 2, 128, false, false>") and same("ggp_kernel<2,2,2,128>", "ggp_kernel<2, 2, 2, 128>")
+    assert not same("ggp_kernel<2,2,2,128>", "ggp_kernel<1, 4, 3, 64>")
+    assert same("wg_kernel<2,2,5,3,x16,split>", "wg_kernel<2, 2, 5, 3, true, 16, true>") and not same("wg_kernel<2,2,5,3,x16>", "wg_kernel<2, 2, 5, 3, true, 16, true>")
+    assert same("wg_kernel<2,2,2,2>", "wg_kernel<2, 2, 2, 2, true, 32>") and not same("wg_kernel<2,2,2,2>", "wg_kernel<2, 2, 2, 2, true, 16>")
+    assert same("gg_kernel<2,2,2,128,kc,split>", "gg_kernel<2, 2, 2, 128, true, true, false, true>")
+    assert same("gg_kernel<1,4,3,64,rc>", "gg_kernel<1, 4, 3, 64, false, true, false>") and not same("gg_kernel<1,4,3,64,rc>", "gg_kernel<1, 4, 3, 64, true, true, false>")
+    assert not same("sgd_kernel", "map2_kernel<add_scalar::{lambda")     # truncated names in the PMC file must not raise
+    rows = [{"kernel": "k", "ms": 2.0, "flops": 4e11, "launches": 4}, {"kernel": "k", "ms": 2.0, "flops": 4e11, "launches": 4},
+            {"kernel": "other", "ms": 9.0, "flops": 1.0, "launches": 1}]
+    one = b.one_stream_fields(rows, "k")["one_stream"]
+    assert one["achieved"] == 200.0 and one["launches"] == 8 and one["avg_launch_ms"] == 0.5 and abs(one["frac"] - 200.0 / 157.3) < 1e-4
+    assert b.one_stream_fields(rows, "absent") == {} and b.one_stream_fields(None, "k") == {}
