@@ -65,7 +65,7 @@ struct GGParams {
   int TX, TYX;        // taps: k = ch*TYX + a*TX + b   (channel-major, KC == 0)
   int ablate;         // ggp_kernel timing diagnostic (CONVNET_GG_ABLATE; results are WRONG): 1 = every staging load reads the zero page
                       // (address work and LDS-DMA issue kept, no memory traffic), 2 = no staging after the second chunk
-  int apre;           // ggp_kernel split build: A is the pre-split bf16-plane image of the bank (split_planes_kernel)
+  int apre;           // ggp_kernel split build: A is the pre-split bf16-plane image of the bank (filter_planes_kernel / dgrad_filter_planes_kernel)
   int KC;             // > 0 (ggp_kernel): reduction order k = ((cb*TYX + tap)*BK + c16, channel ch = cb*BK + c16 of KC — every chunk of BK
                       // k-rows is ONE tap of one 16-channel block, taps innermost — over a filter bank re-laid to match
   int SH, SW;         // source image
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
 // (channel, tap_y, tap_x) is wave-uniform and lives in SGPRs; a lane's (wave-column, image quad) never changes.  Same MFMA order,
 // same epilogue, same tile selection as gg_kernel: results are bit-identical to it.
 // -------------------------------------------------------------------------------------------------
-// APRE (with SPLIT): the A operand arrives ALREADY split — split_planes_kernel turned the re-laid filter bank into bf16 planes
+// APRE (with SPLIT): the A operand arrives ALREADY split — filter_planes_kernel / dgrad_filter_planes_kernel write the re-laid filter bank as bf16 planes
 // [chunk][plane h/m/l][k-group lh][row][8 x bf16 = k-slots j of k-rows 2j + lh], so a lane's A fragment of one plane is ONE ds_read_b128
 // and a third of the loop's split VALU is gone (the bank is a few MB and is rewritten every call anyway).
 template <int WR, int WC, int MT, int CW, bool SPLIT = false, bool APRE = false>
@@ -1162,24 +1162,52 @@ __global__ void filter_tapmajor_kernel(const float* __restrict__ W, float* __res
   }
 }
 
-// A operand of ggp_kernel<…, SPLIT, APRE>: the re-laid fp32 bank Wt[(16*chunk + krow)*R + row] becomes bf16 planes
-// out[(((chunk*3 + plane)*2 + lh)*R + row)*8 + j] = plane(h/m/l) of Wt[(16*chunk + 2j + lh)*R + row]  (exact split, Split8).
-__global__ void split_planes_kernel(const float* __restrict__ Wt, u32x4* __restrict__ out, int chunks, int R) {
-  const size_t total = (size_t)chunks * 2 * R;
+// A operand of ggp_kernel<…, SPLIT, APRE>: bf16 planes of the re-laid bank, R rows per k-row, 16 k-rows per chunk:
+// out[(((chunk*3 + plane)*2 + lh)*R + row)*8 + j] = plane(h/m/l) of bank(row, k-row 2j + lh of the chunk)  (exact split, Split8).
+// The two re-layouts and the split in one pass each (what conv_up_impl / conv_down_impl launch on the pre-split path): thread =
+// (chunk, k-group lh, row); its 8 k-slots j are the chunk's k-rows 2j + lh.
+// forward bank: rows f, chunk = tap + TYX*cb, k-row = channel 16*cb + (2j + lh)
+__global__ void filter_planes_kernel(const float* __restrict__ W, u32x4* __restrict__ out, int F, int C, int TYX) {
+  const size_t total = (size_t)(C / 16) * TYX * 2 * F;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int row = (int)(i % R);
-    const size_t r = i / R;
+    const int f = (int)(i % F);
+    const size_t r = i / F;
     const int lh = (int)(r & 1);
     const size_t chunk = r >> 1;
+    const int tap = (int)(chunk % TYX), cb = (int)(chunk / TYX);
     float x[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = Wt[(chunk * 16 + 2 * j + lh) * (size_t)R + row];
+    for (int j = 0; j < 8; ++j) x[j] = W[(size_t)f + (size_t)F * (tap + (size_t)TYX * (16 * cb + 2 * j + lh))];
     Split8 sp;
     split8(x, sp);
-    u32x4* o = out + ((chunk * 3) * 2 + lh) * (size_t)R + row;
+    u32x4* o = out + ((chunk * 3) * 2 + lh) * (size_t)F + f;
     o[0] = sp.h;
-    o[2 * (size_t)R] = sp.m;
-    o[4 * (size_t)R] = sp.l;
+    o[2 * (size_t)F] = sp.m;
+    o[4 * (size_t)F] = sp.l;
+  }
+}
+// one stride class of the input-gradient bank: rows c, chunk = tap + TYXc*fb, k-row = filter 16*fb + (2j + lh)
+__global__ void dgrad_filter_planes_kernel(const float* __restrict__ W, u32x4* __restrict__ out, int F, int C, int Ky, int Kx, int cy, int cx,
+                                           int sy, int sx, int TYc, int TXc) {
+  const int TYXc = TYc * TXc;
+  const size_t total = (size_t)(F / 16) * TYXc * 2 * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t r = i / C;
+    const int lh = (int)(r & 1);
+    const size_t chunk = r >> 1;
+    const int tap = (int)(chunk % TYXc), fb = (int)(chunk / TYXc);
+    const int a = tap / TXc, b = tap - a * TXc;
+    const float* wp = W + (size_t)F * ((cx + sx * b) + Kx * ((cy + sy * a) + (size_t)Ky * c)) + 16 * fb + lh;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = wp[2 * j];
+    Split8 sp;
+    split8(x, sp);
+    u32x4* o = out + ((chunk * 3) * 2 + lh) * (size_t)C + c;
+    o[0] = sp.h;
+    o[2 * (size_t)C] = sp.m;
+    o[4 * (size_t)C] = sp.l;
   }
 }
 
@@ -2001,19 +2029,9 @@ ConvGeo conv_geo(const Shape4D* img, const Shape4D* flt, const Shape4D* out, con
   return g;
 }
 
-// bf16-plane image of a re-laid bank of `elems` floats with R rows per k-row (split_planes_kernel); `out` holds 1.5 x elems floats
 inline bool gg_presplit_mode() {
   static const bool off = getenv("CONVNET_GG_NO_PRESPLIT") != nullptr;
   return gg_split_mode() && !off;
-}
-void presplit_bank(const float* bank, float* out, size_t elems, int R, const char* op) {
-  const int chunks = (int)(elems / ((size_t)16 * R));
-  CHIP_REQUIRE((size_t)chunks * 16 * R == elems);
-  const size_t work = (size_t)chunks * 2 * R;
-  int nb = (int)((work + 255) / 256);
-  if (nb > 2048) nb = 2048;
-  KernelTimer timer("split_planes_kernel", op, 0.0, 10.0 * elems);
-  hipLaunchKernelGGL(split_planes_kernel, dim3(nb), dim3(256), 0, stream(), bank, reinterpret_cast<u32x4*>(out), chunks, R);
 }
 
 void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* targets, Shape4D* is, Shape4D* fs, Shape4D* ts,
@@ -2032,19 +2050,24 @@ void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* tar
   if (vec && ggp_shape_ok(g.F, g.C)) {
     // producer-wave kernel: the reduction runs tap-major over a re-laid copy of the filter bank (a few MB, ~5 us)
     const size_t welems = (size_t)g.F * p.K;
-    const bool pre = gg_presplit_mode();
-    float* wt = (p.TYX > 1 || pre) ? static_cast<float*>(workspace_aux(sizeof(float) * (welems + (pre ? welems + welems / 2 : 0)))) : nullptr;
-    if (p.TYX > 1) {
+    if (gg_presplit_mode()) {
+      // the consumers read the bank as ready-made bf16 planes: tap-major re-layout and exact three-way split in one pass
+      float* planes = static_cast<float*>(workspace_aux(sizeof(float) * (welems + welems / 2)));
+      const size_t work = (size_t)(g.C / 16) * p.TYX * 2 * g.F;
+      int nb = (int)((work + 255) / 256);
+      if (nb > 2048) nb = 2048;
+      KernelTimer timer("filter_planes_kernel", "conv_fprop", 0.0, 10.0 * welems);
+      hipLaunchKernelGGL(filter_planes_kernel, dim3(nb), dim3(256), 0, stream(), filters->data_device, reinterpret_cast<u32x4*>(planes), g.F, g.C,
+                         p.TYX);
+      p.A = planes;
+      p.apre = 1;
+    } else if (p.TYX > 1) {
+      float* wt = static_cast<float*>(workspace_aux(sizeof(float) * welems));
       int nb = (int)((welems + 255) / 256);
       if (nb > 2048) nb = 2048;
       KernelTimer timer("filter_tapmajor_kernel", "conv_fprop", 0.0, 8.0 * welems);
       hipLaunchKernelGGL(filter_tapmajor_kernel, dim3(nb), dim3(256), 0, stream(), filters->data_device, wt, g.F, g.C, p.TYX);
       p.A = wt;
-    }
-    if (pre) {   // the consumers read the bank as ready-made bf16 planes
-      presplit_bank(p.A, wt + welems, welems, g.F, "conv_fprop");
-      p.A = wt + welems;
-      p.apre = 1;
     }
     p.KC = g.C;
   }
@@ -2106,7 +2129,7 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
   GGClassTable ct{};
   const bool tapm = vec && ggp_shape_ok(g.C, g.F);   // producer-wave kernel: k = tap*F + f over tap-major class filters
   if (tapm) base.KC = g.F;
-  const bool pre = tapm && gg_presplit_mode();        // ... reading the class banks as bf16 planes (split_planes_kernel)
+  const bool pre = tapm && gg_presplit_mode();        // ... reading the class banks as bf16 planes (dgrad_filter_planes_kernel)
   float* const planes = wt + wt_floats;
   if (pre) base.apre = 1;
   const bool multi = g.sy * g.sx > 1 && g.sy * g.sx <= kMaxClasses;   // all classes in one launch (no wave-quantisation per class)
@@ -2142,19 +2165,24 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
       float* wc = wt + woff;
       const size_t welems = (size_t)g.C * g.F * TYc * TXc;
       woff += (welems + 63) / 64 * 64;
-      if (welems > 0) {
+      GGClass k{};
+      k.A = wc; k.K = g.F * TYc * TXc;
+      if (pre && welems > 0) {
+        // class bank straight to bf16 planes (re-layout + exact split in one pass)
+        float* pc = planes + (size_t)(wc - wt) / 2 * 3;
+        const size_t work = (size_t)(g.F / 16) * TYc * TXc * 2 * g.C;
+        int nb = (int)((work + 255) / 256);
+        if (nb > 2048) nb = 2048;
+        KernelTimer timer("dgrad_filter_planes_kernel", "conv_dgrad", 0.0, 10.0 * welems);
+        hipLaunchKernelGGL(dgrad_filter_planes_kernel, dim3(nb), dim3(256), 0, stream(), filters->data_device, reinterpret_cast<u32x4*>(pc), g.F,
+                           g.C, g.Ky, g.Kx, cy, cx, g.sy, g.sx, TYc, TXc);
+        k.A = pc;
+      } else if (welems > 0) {
         int nb = (int)((welems + 255) / 256);
         if (nb > 2048) nb = 2048;
         KernelTimer timer("dgrad_filter_kernel", "conv_dgrad", 0.0, 8.0 * welems);
         hipLaunchKernelGGL(dgrad_filter_kernel, dim3(nb), dim3(256), 0, stream(), filters->data_device, wc, g.F, g.C, g.Ky,
                            g.Kx, cy, cx, g.sy, g.sx, TYc, TXc, tapm ? 1 : 0);
-      }
-      GGClass k{};
-      k.A = wc; k.K = g.F * TYc * TXc;
-      if (pre && welems > 0) {
-        float* pc = planes + (size_t)(wc - wt) / 2 * 3;
-        presplit_bank(wc, pc, welems, g.C, "conv_dgrad");
-        k.A = pc;
       }
       k.GX = GX; k.G = GY * GX; k.TX = TXc > 0 ? TXc : 1; k.TYX = TYc * TXc > 0 ? TYc * TXc : 1;
       k.y0 = jy0; k.x0 = jx0; k.dy0 = iy0; k.dx0 = ix0;
