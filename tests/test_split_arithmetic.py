@@ -99,3 +99,62 @@ def test_split_reduction_is_as_accurate_as_an_fp32_dot_product():
         assert e_split.max() <= 4 * 2.0 ** -24, (K, e_split.max() / 2.0 ** -24)
         if K >= 64:
             assert np.sqrt((e_split ** 2).mean()) <= np.sqrt((e_fp32 ** 2).mean()), (K, e_split.mean(), e_fp32.mean())
+
+
+def _planes_from_bank(bank):
+    """bank[k, row] (k-rows of 16-deep chunks) -> planes[chunk, plane, lh, row, j]: k-slot j of k-group lh is k-row 2j + lh of the chunk
+    (the layout ggp_kernel<..., SPLIT, APRE> stages: DESIGN.md section 2.1b)."""
+    K, R = bank.shape
+    out = np.zeros((K // 16, 3, 2, R, 8), np.float32)
+    for lh in range(2):
+        for j in range(8):
+            h, m, l = split3(bank[2 * j + lh::16])          # rows (chunk, row)
+            out[:, 0, lh, :, j], out[:, 1, lh, :, j], out[:, 2, lh, :, j] = h, m, l
+    return out
+
+
+def test_filter_plane_layouts_equal_relayout_then_split():
+    """filter_planes_kernel / dgrad_filter_planes_kernel (csrc/gather_gemm.hip) index the reference's filter bank
+    W[f + F*(kx + Kx*(ky + Ky*c))] directly; restated here and compared with the two-step definition: tap-major re-layout of the bank
+    (filter_tapmajor_kernel / dgrad_filter_kernel's tap_major order), then the per-chunk plane split."""
+    rng = np.random.default_rng(5)
+    F, C, Ky, Kx = 32, 48, 3, 5
+    W = rng.standard_normal(F * Kx * Ky * C).astype(np.float32)
+    w = lambda f, ky, kx, c: W[f + F * (kx + Kx * (ky + Ky * c))]
+    TYX = Ky * Kx
+    # forward: k = (cb*TYX + tap)*16 + c16, rows f
+    bank = np.zeros((C * TYX, F), np.float32)
+    for cb in range(C // 16):
+        for tap in range(TYX):
+            for c16 in range(16):
+                bank[(cb * TYX + tap) * 16 + c16] = [W[f + F * (tap + TYX * (16 * cb + c16))] for f in range(F)]
+    want = _planes_from_bank(bank)
+    got = np.zeros_like(want)
+    for chunk in range(C // 16 * TYX):
+        tap, cb = chunk % TYX, chunk // TYX
+        for lh in range(2):
+            for f in range(F):
+                x = np.array([W[f + F * (tap + TYX * (16 * cb + 2 * j + lh))] for j in range(8)], np.float32)
+                got[chunk, 0, lh, f], got[chunk, 1, lh, f], got[chunk, 2, lh, f] = split3(x)
+    assert np.array_equal(got, want)
+    # input gradient, stride class (cy, cx) of a stride-(2, 2) convolution: k = (fb*TYXc + tap)*16 + f16, rows c
+    sy = sx = 2
+    for cy, cx in ((0, 0), (1, 0), (1, 1)):
+        TYc, TXc = -(-(Ky - cy) // sy), -(-(Kx - cx) // sx)
+        TYXc = TYc * TXc
+        bank = np.zeros((F * TYXc, C), np.float32)
+        for fb in range(F // 16):
+            for a in range(TYc):
+                for b in range(TXc):
+                    for f16 in range(16):
+                        bank[(fb * TYXc + b + TXc * a) * 16 + f16] = [w(16 * fb + f16, cy + sy * a, cx + sx * b, c) for c in range(C)]
+        want = _planes_from_bank(bank)
+        got = np.zeros_like(want)
+        for chunk in range(F // 16 * TYXc):
+            tap, fb = chunk % TYXc, chunk // TYXc
+            a, b = tap // TXc, tap % TXc
+            for lh in range(2):
+                for c in range(C):
+                    base = F * ((cx + sx * b) + Kx * ((cy + sy * a) + Ky * c)) + 16 * fb + lh
+                    got[chunk, 0, lh, c], got[chunk, 1, lh, c], got[chunk, 2, lh, c] = split3(W[base:base + 16:2])
+        assert np.array_equal(got, want), (cy, cx)
