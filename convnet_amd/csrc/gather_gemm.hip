@@ -1,4 +1,4 @@
-// fp32-MFMA implicit-GEMM kernels for the conv_edge / fc_edge hot path on gfx950.
+// Implicit-GEMM kernels for the conv_edge / fc_edge hot path on gfx950: fp32 operands, fp32 accumulation, fp32 results.
 //
 // Everything the reference lowers to im2col + cublasSgemm + scatter (cudamat_conv_gemm.cu:545-960:
 // _convUpGemm / _convDownGemm / _convOutpGemm) and cublasSgemm for FC (cudamat.cu:2130-2152) is
@@ -19,6 +19,11 @@
 // contiguous dimension of every activation, so it is mapped to the D *column* (lane) dimension:
 // loads of 4 consecutive images per lane are one ds_read_b128 / global dwordx4 and stores are
 // 512 contiguous bytes per half-wave.  64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak (fp32 matrix).
+//
+// Two matrix paths, chosen per launch (matrix_path(), include/convnet_hip.h: convnet_hip_set_matrix_path): the products are formed
+// either by that fp32 instruction or — the default — on the bf16 pipe from EXACT three-way operand splits, six
+// v_mfma_f32_32x32x16_bf16 per 32x32x16 block (Split8 / split8 / split_mac below; same C/D layout, so tiles, epilogues and launch
+// logic are shared).  ggp_kernel is gg_kernel with a producer wave; its split build can read the A operand as pre-split planes.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
