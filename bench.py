@@ -15,15 +15,17 @@ bracketed by barrier + torch.cuda.synchronize().
 
 Extra objects on the line:
   roofline      dominant MFMA kernel: algorithmic flops / HIP-event time measured per launch inside
-                the timed region, against the fp32-matrix peak (157.3 TFLOP/s: operands, accumulation
-                and results are fp32 — grad_check needs it).  Also `model_frac` = whole-step algorithmic
-                flops / step time / peak, and per-kernel-family rows under `families`.  With the default
-                matrix path the kernels form the fp32 products on the bf16 matrix pipe from exact three-way
-                operand splits (six bf16 MFMAs per 32x32x16 block; include/convnet_hip.h), so `frac` can
-                exceed 1; `roofline.pipe` prices the same launches against the pipe they execute on
-                (6 executed bf16 flops per algorithmic flop, 2.5 PFLOP/s dense bf16 peak).
-                With the second stream on (default) a launch's duration includes what the co-running kernel of the
-                other stream took — `roofline.one_stream` gives the dominant kernel's rate without a neighbour.
+                the timed region, against the peak of the matrix pipe the kernel EXECUTES on.  With the default
+                matrix path the fp32 products are formed on the bf16 pipe from exact three-way operand splits —
+                six v_mfma_f32_32x32x16_bf16 per 32x32x16 block (include/convnet_hip.h) — so one algorithmic flop
+                costs six bf16 flops and the ceiling in algorithmic units is 2500 / 6 = 416.7 TFLOP/s; `frac` =
+                achieved / 416.7 (the same number as executed bf16 flops / 2500).  With --matrix-path fp32 the peak is
+                the fp32 matrix instruction's 157.3 TFLOP/s.  No fraction on the line can exceed 1; the ratio to the
+                fp32-instruction peak travels only as the labelled extra `vs_fp32_instruction_peak`.  Also
+                `model_frac` = whole-step algorithmic flops / step time / the same peak, and per-family rows under
+                `families`.  With the second stream on (default) a launch's duration includes what the co-running
+                kernel of the other stream took — `roofline.one_stream` gives the dominant kernel's rate without a
+                neighbour.
   fp32_mfma_path  the same step with every GEMM kernel on v_mfma_f32_32x32x2_f32 instead (--matrix-path fp32),
                 timed in this process right after the main run (rank 0, N=1 only): the number to read if the
                 bf16-split products are not accepted as fp32 arithmetic.
@@ -94,6 +96,12 @@ def pmc_traffic(kernel, args):
     return {"traffic": None}
 
 
+def kernel_peak(name):
+    """Peak of the pipe a GEMM kernel family executes on, in ALGORITHMIC fp32 TFLOP/s: the bf16-split builds (",split" in the name)
+    issue SPLIT_PRODUCTS bf16 MFMA flops per algorithmic flop on the 2.5 PFLOP/s dense bf16 pipe; the others use the fp32 instruction."""
+    return PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS if ",split" in name else PEAK_FP32_MATRIX_TFLOPS
+
+
 def one_stream_fields(rows, kernel):
     """`roofline.one_stream`: the dominant kernel's rate in the extra one-stream steps (no co-running kernel)."""
     rows = [r for r in (rows or []) if r["kernel"] == kernel]
@@ -101,7 +109,7 @@ def one_stream_fields(rows, kernel):
     if not rows or ms <= 0:
         return {}
     tf = flops / (ms * 1e-3) / 1e12
-    return {"one_stream": {"achieved": round(tf, 2), "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4), "avg_launch_ms": round(ms / n, 4), "launches": n,
+    return {"one_stream": {"achieved": round(tf, 2), "frac": round(tf / kernel_peak(kernel), 4), "avg_launch_ms": round(ms / n, 4), "launches": n,
                            "note": "the same kernel in 4 extra steps with everything on one stream (no co-running kernel), after the timed region"}}
 
 
@@ -198,6 +206,27 @@ def ref_host_leg(args):
         return {"value": None, "note": f"failed: {e!r}"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): become the launcher — N ranks of this same
+    command under torch.distributed.run on 127.0.0.1, one per GPU; rank 0 of the children prints the ONE JSON line on our stdout."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs (one process per GPU), this box has {have}; "
+                         f"nothing was run\n")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver (RCCL needs it)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,6 +262,8 @@ def main():
                     help="skip the `ref_host` leg (the reference's own unmodified C++ ConvNet::TrainOneBatch loop linked to this library, "
                          "tools/ref_host_bench.py, timed in a child process after the product run; rank 0, 1 GPU only)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     # RCCL prints a version banner on the C-level stdout at communicator creation; keep the real stdout
     # for the single JSON line and send everything else (python and C) to stderr.
@@ -251,7 +282,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; nothing was run\n")
+        sys.exit(2)
     strong = args.global_batch > 0
     if strong:
         assert args.global_batch % world == 0, f"--global-batch {args.global_batch} does not divide over {world} ranks"
@@ -291,6 +324,9 @@ def main():
     step_flops = 2.0 * train_macs * args.batch
 
     def sync_all():
+        # device first: with --transport abi the library's own communicator must be idle before a torch collective runs
+        # (two communicators in one process: data_parallel.GradientExchange._drain_library_comm)
+        torch.cuda.synchronize()
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
@@ -353,8 +389,14 @@ def main():
         _lib.lib.convnet_hip_set_matrix_path(1 if args.matrix_path == "split" else 0)
         other = {"matrix_path": other_name, "value": round(args.batch * args.steps / dt_other, 2), "unit": "images/sec",
                  "ms_per_step": round(1e3 * dt_other / args.steps, 3), "steps": args.steps,
-                 "model_frac": round(step_flops / (dt_other / args.steps) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4)}
+                 "model_frac": round(step_flops / (dt_other / args.steps) / 1e12 /
+                                     (PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS if other_name == "split" else PEAK_FP32_MATRIX_TFLOPS), 4)}
 
+    # ranks that actually took part in the gradient exchange: the process group's size, and for the C-ABI transport the library's own
+    # communicator (convnet_hip_comm_size); 0 = no exchange (one GPU)
+    rccl_ranks = 0
+    if exchange is not None:
+        rccl_ranks = _lib.lib.convnet_hip_comm_size() if args.transport == "abi" else dist.get_world_size()
     if rank == 0:
         images = args.batch * world * args.steps
         value = images / dt
@@ -372,29 +414,41 @@ def main():
             executed = dom["executed"] / (dom["ms"] * 1e-3) / 1e12
             all_flops = sum(v["flops"] for v in mfma.values())
             all_ms = sum(v["ms"] for v in mfma.values())
+            split_dom = ",split" in dom_name
+            peak = kernel_peak(dom_name)
+            step_peak = PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS if args.matrix_path == "split" else PEAK_FP32_MATRIX_TFLOPS
+            # every MFMA family priced on its own pipe: sum of (family time at its peak) / sum of measured family time
+            all_ideal_ms = sum(v["flops"] / (kernel_peak(k) * 1e12) * 1e3 for k, v in mfma.items())
             roofline = {
-                "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
+                "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": round(peak, 2),
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "peak_note": ("algorithmic fp32 TFLOP/s the executed pipe can deliver: 2500 dense bf16 / 6 bf16 MFMA flops per fp32 product "
+                              "(v_mfma_f32_32x32x16_bf16, exact three-way operand splits)") if split_dom else
+                             "v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD",
                 # `achieved` counts ALGORITHMIC flops (2*N*My*Mx*F*C*Ky*Kx for every conv direction, 2*M*N*K for FC); `executed`
                 # also counts the MFMA work a dgrad gather spends on border taps that read the zero page
-                "executed": round(executed, 2), "executed_frac": round(executed / PEAK_FP32_MATRIX_TFLOPS, 4),
+                "executed": round(executed, 2), "executed_frac": round(executed / peak, 4),
+                "vs_fp32_instruction_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
                 **pmc_traffic(dom_name, args),
                 "flops_per_launch": dom["flops"] / dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                 "launches": dom["launches"], "sampled_steps": timed_steps,
                 "all_mfma_kernels": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
-                                     "frac": round(all_flops / (all_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+                                     "frac": round(all_ideal_ms / all_ms, 4),
                                      "ms_per_step": round(all_ms / timed_steps, 3)},
-                "model_frac": round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
+                "model_frac": round(step_flops / (ms_per_step * 1e-3) / 1e12 / step_peak, 4),
+                "model_vs_fp32_instruction_peak": round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
                 **({"pipe": {"instruction": "v_mfma_f32_32x32x16_bf16", "executed_per_algorithmic_flop": SPLIT_PRODUCTS,
                              "achieved": round(SPLIT_PRODUCTS * (executed if executed > 0 else achieved), 1), "peak": PEAK_BF16_MATRIX_TFLOPS,
                              "unit": "TFLOP/s (bf16, executed)",
                              "frac": round(SPLIT_PRODUCTS * (executed if executed > 0 else achieved) / PEAK_BF16_MATRIX_TFLOPS, 4)}}
-                   if ",split" in dom_name else {}),
+                   if split_dom else {}),
                 **one_stream_fields(prof_one_stream, dom_name),
                 "families": {k: {"launches_per_step": v["launches"] / timed_steps, "ms_per_step": round(v["ms"] / timed_steps, 4),
                                  **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                     "executed_tflops": round(v["executed"] / (v["ms"] * 1e-3) / 1e12, 2)} if v["flops"] > 0 else
-                                    {"gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)})}
+                                     "executed_tflops": round(v["executed"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                     "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / kernel_peak(k), 4)} if v["flops"] > 0 else
+                                    {"gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                     "frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})}
                              for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
                 "ops": {f'{r["kernel"]}|{r["op"]}': round(r["ms"] / timed_steps, 4) for r in sorted(prof, key=lambda r: -r["ms"])},
             }
@@ -403,6 +457,7 @@ def main():
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "host_enqueue_ms_per_step": round(1e3 * dt_enqueue / args.steps, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "rccl_ranks": rccl_ranks,
             "arithmetic": ("fp32 operands, fp32 accumulation, fp32 results; GEMM products formed on the bf16 matrix pipe from exact three-way "
                            "operand splits, 6 of 9 cross terms (dropped terms <= 2^-23 of a product; measured max error 4.08 x 2^-24 of sum|ab| at "
                            "K=3456 vs 4.55 x 2^-24 for the fp32 matrix instruction, tools/split_gemm.hip); same parity tests and tolerances as "
@@ -429,6 +484,8 @@ def main():
         if world == 1 and not args.no_ref_host and args.model in ("alexnet", "alexnet_nin") and not args.staged_input:
             out["ref_host"] = ref_host_leg(args)
         result_line = json.dumps(out)
+    if exchange is not None:
+        exchange.Close()
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:

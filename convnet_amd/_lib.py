@@ -102,6 +102,7 @@ def _load():
     sig("convnet_hip_comm_init", I, I, I, ctypes.c_char_p)
     sig("convnet_hip_comm_rank", I)
     sig("convnet_hip_comm_size", I)
+    sig("convnet_hip_comm_max_slots", I)
     sig("convnet_hip_comm_broadcast", I, P(cudamat), I)
     sig("convnet_hip_comm_allreduce_avg", I, P(cudamat), ctypes.c_size_t, ctypes.c_size_t, I)
     sig("convnet_hip_comm_wait", I, I)

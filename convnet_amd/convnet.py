@@ -362,12 +362,21 @@ class ConvNet(TrainLoopMixin):
         return [l.GetPerformanceMetric() for l in self.output_layers_]
 
     def TimestampModel(self):
-        """ConvNet::TimestampModel (src/convnet.cc:830-838): stamp the run so checkpoints are <dir>/<name>_<timestamp>.h5."""
+        """ConvNet::TimestampModel (src/convnet.cc:830-838): stamp the run — checkpoints go to <dir>/<name>_<timestamp>.h5 — append
+        the stamp to the model, write the stamped model as <dir>/<name>_<timestamp>.pbtxt and name the two log files."""
+        import os
         import time
+        from . import pbtxt
         ts = time.strftime("%Y%m%d%H%M%S")
-        if self.model_.timestamp is None:
-            self.model_.timestamp = []
+        if self.model_.timestamp and ts <= self.model_.timestamp[-1]:   # a resume within the same second must not reuse the name
+            ts = str(int(self.model_.timestamp[-1]) + 1)
         self.model_.timestamp.append(ts)
+        fname = os.path.join(self.model_.checkpoint_dir, f"{self.model_.name}_{ts}")
+        if self.model_.checkpoint_dir:
+            os.makedirs(self.model_.checkpoint_dir, exist_ok=True)
+            pbtxt.write(fname + ".pbtxt", self.model_)
+        self.log_file_ = fname + "_train.log"
+        self.val_log_file_ = fname + "_valid.log"
         return ts
 
     def ReadCorrectCount(self, reset=True):

@@ -16,9 +16,20 @@
 #include <cstring>
 #include <string>
 
-#include <rccl/rccl.h>
-
 #include "common.h"
+
+// The handful of RCCL declarations this file uses, stated locally so the library builds where the RCCL development headers are
+// not installed (it never links librccl: every entry point is looked up with dlsym at comm_init).  Values are the NCCL ABI's
+// (rccl.h: ncclSuccess 0, ncclSum 0, ncclFloat 7, NCCL_UNIQUE_ID_BYTES 128).
+struct ncclComm;
+typedef ncclComm* ncclComm_t;
+struct ncclUniqueId { char internal[128]; };
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclRedOp_t ncclSum = 0;
+constexpr ncclDataType_t ncclFloat = 7;
 
 namespace chip {
 namespace {
@@ -114,6 +125,8 @@ int convnet_hip_comm_init(int rank, int nranks, const char* id_in) {
 
 int convnet_hip_comm_rank(void) { return g_rank; }
 int convnet_hip_comm_size(void) { return g_nranks; }
+// slots [0, max_slots) exist; a host plans its posts per step against this number BEFORE the backward pass starts
+int convnet_hip_comm_max_slots(void) { return kSlots; }
 
 // ConvNet::Broadcast (src/convnet.cc:407-413): root's copy of `mat` to every rank, ordered after the compute stream's work
 // and complete (host-synchronised) on return — it runs once, after initialisation.

@@ -77,8 +77,12 @@ struct GGParams {
   int ssy, ssx, y0, x0, dir;       // source row of tap a: oy*ssy + y0 + dir*a
   int DW, DP;         // dest image width, pixels per channel (DH*DW)
   int dsy, dsx, dy0, dx0;          // dest pixel: (oy*dsy + dy0, ox*dsx + dx0)
-  int nblk;           // ceil(N/128) wave-columns per pixel
-  int ncols;          // G*nblk wave-columns in total
+  int NP;             // column pitch of one output pixel.  The column space of the GEMM is FLAT: column q = m*NP + n is image n of
+                      // output pixel m, and wave-column `colid` owns columns [colid*CW, colid*CW + CW).  Vector path: NP = N (N % 4 == 0,
+                      // so a 16-byte piece never straddles pixels) — a wave-column spans CW/N pixels when N < CW, and no MFMA column
+                      // is padding at any batch size (round 2 gave every pixel ceil(N/CW) wave-columns of its own: at 32 images per GPU
+                      // three quarters of every MFMA column were zeros).  Scalar path: NP = ceil(N/CW)*CW, the padded form.
+  int ncols;          // ceil(G*NP / CW) wave-columns in total
   int row_tiles, col_tiles;
   int chunks_per_split;  // in BK units
   int splits;
@@ -94,6 +98,8 @@ struct GGParams {
   int tail_first, tail_splits, tail_cps, tail_tf8, tail_tt8;
   float* tail_partial;
   int prio;            // issue priority scheme of the main loop (gg_prio_mode())
+  int skinny;          // host only: the whole column space is <= 128 columns (an FC layer at <= 128 images per GPU): gg_run picks the
+                       // 128-row x 64-column tile instead of padding a 256-column one with zeros
 };
 
 // A strided dgrad is one gather-GEMM per stride class (conv_down_impl); the classes differ only in the fields
@@ -134,7 +140,7 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
 // options (fin), or store the raw sums into this split's slab.  Shared by gg_kernel and gg_tail_fix_kernel.
 template <int WR, int WC, int MT, int CW, bool VEC>
 __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT][CW / 32], int row_tile, int col_tile, int split,
-                                            int pncols, int pGX, int pdy0, int pdx0) {
+                                            int pncols, int pGX, int pG, int pdy0, int pdx0) {
   constexpr int NTC = CW / 32;
   using fvec = __attribute__((ext_vector_type(NTC))) float;
   constexpr int ROWS = WR * MT * 32;
@@ -146,11 +152,11 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT]
   const int N = p.N;
   const int colid = col_tile * WC + wc;
   if (colid >= pncols) return;
-  const int m = colid / p.nblk, blk = colid - m * p.nblk;
+  const int q = colid * CW + NTC * li;   // flat column (GGParams::NP)
+  const int m = q / p.NP, n = q - m * p.NP;
+  if (m >= pG || n >= N) return;
   const int oy = m / pGX, ox = m - oy * pGX;
   const int dpix = (oy * p.dsy + pdy0) * p.DW + ox * p.dsx + pdx0;
-  const int n = blk * CW + NTC * li;
-  if (n >= N) return;
   float* base = (p.splits > 1 ? p.partial + (size_t)split * p.slab : p.dst) + (size_t)dpix * N + n;
   const bool fin = p.splits == 1;
 #pragma unroll
@@ -208,7 +214,8 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT]
 }
 
 // -------------------------------------------------------------------------------------------------
-// fp32 products on the bf16 matrix pipe (CONVNET_GG_SPLIT=1, opt-in): every operand value is split EXACTLY into three bf16
+// fp32 products on the bf16 matrix pipe (the default matrix path; convnet_hip_set_matrix_path / CONVNET_GG_SPLIT=0 select the fp32
+// instruction instead): every operand value is split EXACTLY into three bf16
 // terms, x = h + m + l with h = rne8(x), m = rne8(x - h), l = x - h - m (the second residual has at most 8 significant bits), and
 // a*b is accumulated in fp32 as hh + hm + mh + hl + lh + mm by six v_mfma_f32_32x32x16_bf16.  The three dropped cross terms
 // (ml, lm, ll) are below 2^-23 of the product.  tools/split_gemm.hip measures it against double on conv4's reduction length:
@@ -236,6 +243,18 @@ __device__ __forceinline__ void split8(const float (&x)[8], Split8& s) {
     s.m[q] = M;
     s.l[q] = pk_bf16(s0, s1);
   }
+}
+// Range of the split.  h = rne8(x) is finite for |x| <= 0x7F7F7FFF (3.396e38); above it — the top 0.2 % of the fp32 range and +-inf —
+// h is a bf16 inf and the residual x - h is NaN.  The in-loop split8 above carries no range check (one more VALU per element in
+// loops that are VALU-limited): such an ACTIVATION / DERIVATIVE value makes the outputs it touches NaN where the fp32 instruction
+// gives +-inf or a huge finite number (documented in include/convnet_hip.h, pinned by tests/test_split_arithmetic_gpu.py).  The
+// FILTER operand is split outside the loops (filter_planes_kernel, dgrad_filter_planes_kernel) and saturates instead: +-inf and
+// above-range finite values enter as +-bf16 max (3.3895e38); NaN stays NaN.
+__device__ __forceinline__ void split8_sat(float (&x)[8], Split8& s) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (fabsf(x[j]) > __uint_as_float(0x7F7F7FFFu)) x[j] = copysignf(__uint_as_float(0x7F7F0000u), x[j]);   // false for NaN
+  split8(x, s);
 }
 __device__ __forceinline__ f32x16 mma_bf16(u32x4 a, u32x4 b, f32x16 c) {
   typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -333,7 +352,6 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
   const float* const pA = T.A;
   const int pK = T.K, pGX = T.GX, pG = T.G, pTX = T.TX, pTYX = T.TYX, py0 = T.y0, px0 = T.x0, pdy0 = T.dy0, pdx0 = T.dx0, pncols = T.ncols;
   const int L = T.L, tsplit = T.tsplit;   // tsplit >= 0: this block computes one K-range of a tail tile
-  (void)pG;
   const int row_tile = L % p.row_tiles, col_tile = L / p.row_tiles;
   const int split = blockIdx.y;
 
@@ -368,12 +386,15 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
     const int wcol = KM ? sub / CW4 : idx / (BK * CW4), krow = KM ? 0 : (idx / CW4) % BK, c4 = KM ? sub % CW4 : idx % CW4;
     const int colid = col_tile * WC + wcol;
     const bool ok = idx < WC * BK * CW4 && colid < pncols;
-    const int m = ok ? colid / p.nblk : 0, blk = ok ? colid % p.nblk : 0;
+    const int q = colid * CW + 4 * c4;   // flat column (GGParams::NP)
+    const int mq = q / p.NP;
+    const bool in = ok && mq < pG;
+    const int m = in ? mq : 0;
     const int oy = m / pGX, ox = m - oy * pGX;
     b_ys0[it] = oy * p.ssy + py0;
     b_xs0[it] = ox * p.ssx + px0;
-    b_n[it] = blk * CW + 4 * c4;
-    b_ok[it] = ok;
+    b_n[it] = in ? q - mq * p.NP : N;   // N: out of range for every guard below
+    b_ok[it] = in;
     b_krow[it] = krow;
     b_lds[it] = (wcol * BK + krow) * CW + 4 * c4;
   }
@@ -747,7 +768,7 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
       }
     return;
   }
-  gg_epilogue<WR, WC, MT, CW, VEC>(p, acc, row_tile, col_tile, split, pncols, pGX, pdy0, pdx0);
+  gg_epilogue<WR, WC, MT, CW, VEC>(p, acc, row_tile, col_tile, split, pncols, pGX, pG, pdy0, pdx0);
 #ifdef CONVNET_GG_TRACE
   trace_out(trace_clock());
 #endif
@@ -805,25 +826,28 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
   if (kend > T.K) kend = T.K;
   int nchunks = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
 
-  // Border-tap skipping.  In tap-major order a whole run of KC/BK chunks belongs to one tap; when every wave-column of the tile
-  // is an image block of ONE output pixel (N >= WC*CW images per pixel) and this block owns the whole reduction, the taps whose
-  // source pixel lies outside the image contribute exact zeros and are left out — producer and consumers walk the rectangle
-  // [a_lo, a_hi] x [b_lo, b_hi] of taps that exist.  (A dgrad gather otherwise issues 1.13x (conv2) to 1.40x (conv5) the algorithmic
+  // Border-tap skipping.  In tap-major order a whole run of KC/BK chunks belongs to one tap; when this block owns the whole
+  // reduction, the taps whose source pixel lies outside the image for EVERY output pixel of the tile contribute exact zeros and
+  // are left out — producer and consumers walk the rectangle [a_lo, a_hi] x [b_lo, b_hi] of taps that exist for some pixel of the
+  // tile (a tile is WC*CW/NP consecutive pixels: one at N = 256, eight at N = 32; a lane whose own pixel lacks a tap of the
+  // rectangle reads the zero page, as before).  (A dgrad gather otherwise issues 1.13x (conv2) to 1.40x (conv5) the algorithmic
   // MACs on the zero page, a padded 3x3 fprop 1.11x.)  It pays on launches of several rounds; a single round ends with its
   // slowest tile.
   const int TYn = T.TYX / T.TX;
   int a_lo = 0, a_hi = TYn - 1, b_lo = 0, b_hi = T.TX - 1;
-  const bool skip = tsplit < 0 && p.splits == 1 && p.nblk % WC == 0;
+  const bool skip = tsplit < 0 && p.splits == 1;
   if (skip) {
-    const int m = (col_tile * WC) / p.nblk;
-    const int oy = m / T.GX, ox = m - oy * T.GX;
-    const int ys0 = oy * p.ssy + T.y0, xs0 = ox * p.ssx + T.x0;
-    if (p.dir > 0) {
-      a_lo = max(0, -ys0); a_hi = min(TYn - 1, p.SH - 1 - ys0);
-      b_lo = max(0, -xs0); b_hi = min(T.TX - 1, p.SW - 1 - xs0);
-    } else {
-      a_lo = max(0, ys0 - (p.SH - 1)); a_hi = min(TYn - 1, ys0);
-      b_lo = max(0, xs0 - (p.SW - 1)); b_hi = min(T.TX - 1, xs0);
+    // pixel range of the tile (row-major): rows oy_f..oy_l; columns ox_f..ox_l when it stays inside one row, else the whole row
+    const int m_f = (col_tile * WC * CW) / p.NP, m_l = min(T.G - 1, ((col_tile + 1) * WC * CW - 1) / p.NP);
+    const int oy_f = m_f / T.GX, oy_l = m_l / T.GX;
+    const int ox_f = oy_f == oy_l ? m_f - oy_f * T.GX : 0, ox_l = oy_f == oy_l ? m_l - oy_l * T.GX : T.GX - 1;
+    const int ys_f = oy_f * p.ssy + T.y0, ys_l = oy_l * p.ssy + T.y0, xs_f = ox_f * p.ssx + T.x0, xs_l = ox_l * p.ssx + T.x0;
+    if (p.dir > 0) {   // tap a exists for source row ys0 iff 0 <= ys0 + a < SH: union over ys0 in [ys_f, ys_l]
+      a_lo = max(0, -ys_l); a_hi = min(TYn - 1, p.SH - 1 - ys_f);
+      b_lo = max(0, -xs_l); b_hi = min(T.TX - 1, p.SW - 1 - xs_f);
+    } else {           // 0 <= ys0 - a < SH
+      a_lo = max(0, ys_f - (p.SH - 1)); a_hi = min(TYn - 1, ys_l);
+      b_lo = max(0, xs_f - (p.SW - 1)); b_hi = min(T.TX - 1, xs_l);
     }
     const int na = a_hi - a_lo + 1, nb2 = b_hi - b_lo + 1;
     nchunks = (na > 0 && nb2 > 0) ? na * nb2 * (p.KC / BK) : 0;
@@ -843,11 +867,13 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
     // lane constants of the B stage: this lane's (wave-column, image quad) and the source pixel of tap (0,0)
     const int wcol = lane / CW4, c4 = lane % CW4;
     const int colid = col_tile * WC + wcol;
-    const bool col_ok = colid < T.ncols;
-    const int m = col_ok ? colid / p.nblk : 0, blk = col_ok ? colid % p.nblk : 0;
+    const int q = colid * CW + 4 * c4;   // flat column (GGParams::NP)
+    const int mq = q / p.NP;
+    const bool col_ok = colid < T.ncols && mq < T.G;
+    const int m = col_ok ? mq : 0;
     const int oy = m / T.GX, ox = m - oy * T.GX;
     const int ys0 = oy * p.ssy + T.y0, xs0 = ox * p.ssx + T.x0;
-    const int bn = blk * CW + 4 * c4;
+    const int bn = q - mq * p.NP;
     const bool b_ok = col_ok && bn < N;
     // Reduction order k = (cb*TYX + tap)*BK + c16 (KC % BK == 0): the BK k-rows of a chunk are BK consecutive channels of ONE tap, so
     // every lane's source pixel (and whether it exists) is fixed for the chunk and k-row `it` is a constant plane stride away — the
@@ -1084,7 +1110,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
       }
     return;
   }
-  gg_epilogue<WR, WC, MT, CW, true>(p, acc, row_tile, col_tile, split, T.ncols, T.GX, T.dy0, T.dx0);
+  gg_epilogue<WR, WC, MT, CW, true>(p, acc, row_tile, col_tile, split, T.ncols, T.GX, T.G, T.dy0, T.dx0);
 }
 
 // Sums the tail_splits partial tiles of one tail tile in fixed order and applies the normal epilogue.
@@ -1106,7 +1132,7 @@ __global__ __launch_bounds__(WR* WC * 64) void gg_tail_fix_kernel(const GGParams
 #pragma unroll
       for (int u = 0; u < NTC; ++u) acc[t][u][reg] = v[u];
     }
-  gg_epilogue<WR, WC, MT, CW, VEC>(p, acc, L % p.row_tiles, L / p.row_tiles, 0, p.ncols, p.GX, p.dy0, p.dx0);
+  gg_epilogue<WR, WC, MT, CW, VEC>(p, acc, L % p.row_tiles, L / p.row_tiles, 0, p.ncols, p.GX, p.G, p.dy0, p.dx0);
 }
 
 // dst = scaleTargets*dst + sum_s slab[s]  (+bias[row], relu) over a full dst extent.
@@ -1184,7 +1210,7 @@ __global__ void filter_planes_kernel(const float* __restrict__ W, u32x4* __restr
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = W[(size_t)f + (size_t)F * (tap + (size_t)TYX * (16 * cb + 2 * j + lh))];
     Split8 sp;
-    split8(x, sp);
+    split8_sat(x, sp);
     u32x4* o = out + ((chunk * 3) * 2 + lh) * (size_t)F + f;
     o[0] = sp.h;
     o[2 * (size_t)F] = sp.m;
@@ -1208,7 +1234,7 @@ __global__ void dgrad_filter_planes_kernel(const float* __restrict__ W, u32x4* _
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = wp[2 * j];
     Split8 sp;
-    split8(x, sp);
+    split8_sat(x, sp);
     u32x4* o = out + ((chunk * 3) * 2 + lh) * (size_t)C + c;
     o[0] = sp.h;
     o[2 * (size_t)C] = sp.m;
@@ -1688,7 +1714,7 @@ void gg_launch_classes(GGParams& p, GGClassTable& ct, bool vec) {
   constexpr int ROWS = WR * MT * 32;
   constexpr int A_STAGE = BK * ROWS, B_STAGE = WC * BK * CW;
   const size_t lds = sizeof(float) * 2 * (A_STAGE + B_STAGE);
-  p.nblk = divup(p.N, CW);
+  p.NP = vec ? p.N : divup(p.N, CW) * CW;
   p.row_tiles = divup(p.R, ROWS);
   p.zero = zero_page();
   p.prio = gg_prio_mode();
@@ -1700,7 +1726,7 @@ void gg_launch_classes(GGParams& p, GGClassTable& ct, bool vec) {
   std::sort(ct.c, ct.c + ct.n, [](const GGClass& a, const GGClass& b) { return a.K > b.K; });
   int end = 0;
   for (int i = 0; i < ct.n; ++i) {
-    ct.c[i].ncols = ct.c[i].G * p.nblk;
+    ct.c[i].ncols = divup(ct.c[i].G * p.NP, CW);
     ct.c[i].col_tiles = divup(ct.c[i].ncols, WC);
     end += p.row_tiles * ct.c[i].col_tiles;
     ct.c[i].tile_end = end;
@@ -1712,7 +1738,7 @@ void gg_launch_classes(GGParams& p, GGClassTable& ct, bool vec) {
   const std::string& kname_s = p.apre ? kname_s1 : kname_s0;
   static const std::string kname_gs = kname_g.substr(0, kname_g.size() - 1) + ",split>";
   const std::string& kname = p.KC > 0 ? (gg_split_mode() ? kname_s : kname_p) : ((vec && gg_split_mode()) ? kname_gs : kname_g);
-  KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, (p.KC > 0 && p.nblk % WC == 0) ? 0.0 : t_exec);
+  KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, p.KC > 0 ? 0.0 : t_exec);
   dim3 grid(end), block(WR * WC * 64);
   if (p.KC > 0) {
     CHIP_REQUIRE(vec && WC * (CW / 4) == 64);
@@ -1747,8 +1773,8 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   constexpr int ROWS = WR * MT * 32;
   constexpr int A_STAGE = AK ? ROWS * (BK + 4) : BK * ROWS;
   constexpr int B_STAGE = WC * BK * CW;
-  p.nblk = divup(p.N, CW);
-  p.ncols = p.G * p.nblk;
+  p.NP = vec ? p.N : divup(p.N, CW) * CW;
+  p.ncols = divup(p.G * p.NP, CW);
   // CONVNET_GG_LDS_PAD (diagnostic): extra dynamic LDS per block, e.g. 65536 to force ONE resident block per CU
   static const size_t lds_pad = [] { const char* e = getenv("CONVNET_GG_LDS_PAD"); return e && *e ? (size_t)atol(e) : (size_t)0; }();
   const size_t lds = sizeof(float) * 2 * (A_STAGE + B_STAGE) + lds_pad;
@@ -1839,7 +1865,7 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   const std::string& kname = p.KC > 0 ? (gg_split_mode() ? kname_s : kname_p) : ((vec && gg_split_mode()) ? kname_gs : kname_g);
   {
     // ggp_kernel leaves out border taps when a tile is one pixel and owns its whole reduction: executed <= algorithmic then
-    const bool skips = p.KC > 0 && splits == 1 && p.nblk % WC == 0;
+    const bool skips = p.KC > 0 && splits == 1;
     KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, skips ? 0.0 : t_exec);
     if constexpr (!AK && WR == 2 && WC == 2 && MT == 2 && CW == 128) {
       if (o3) {
@@ -1901,7 +1927,12 @@ void gg_run(GGParams& p, bool vec, size_t dst_elems) {
   // row tile by problem height: 128 rows (2x2 waves of 64x128), 96 rows (4 waves of 96x64: conv1 fprop,
   // conv2 dgrad), 64 and 32 rows for small layers.
   static const int force64 = getenv("CONVNET_GG_ROWS64") ? 1 : 0;   // experiment knob: 64-row tiles everywhere
-  if (force64) gg_launch_cfg<2, 2, 1, 128, AK>(p, vec, dst_elems);
+  static const bool no_skinny = getenv("CONVNET_GG_NO_SKINNY") != nullptr;
+  // An FC layer at a small per-GPU batch (strong scaling of a global batch: 128 / 64 / 32 images per GPU) is a GEMM with <= 128
+  // columns, bound by streaming the weight matrix once: four waves stacked along the rows, one 64-column wave-column, so a
+  // 32-image batch pads 2x instead of 8x and every weight row still reaches LDS with 16-byte pieces.
+  if (p.skinny && vec && !no_skinny) gg_launch_cfg<4, 1, 1, 64, AK>(p, vec, dst_elems);
+  else if (force64) gg_launch_cfg<2, 2, 1, 128, AK>(p, vec, dst_elems);
   else if (p.R > 96 || (p.R > 64 && p.R <= 96 && (!vec)))
     gg_launch_cfg<2, 2, 2, 128, AK>(p, vec, dst_elems);
   else if (p.R > 64)
@@ -2049,7 +2080,6 @@ void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* tar
   p.GX = g.Mx; p.G = g.My * g.Mx; p.TX = g.Kx; p.TYX = g.Ky * g.Kx;
   p.SH = g.H; p.SW = g.W; p.ssy = g.sy; p.ssx = g.sx; p.y0 = g.py; p.x0 = g.px; p.dir = 1;
   p.DW = g.Mx; p.DP = g.My * g.Mx; p.dsy = 1; p.dsx = 1; p.dy0 = 0; p.dx0 = 0;
-  p.nblk = divup(g.N, 128); p.ncols = p.G * p.nblk;
   p.scaleTargets = scaleTargets; p.relu = relu;
   const bool vec = g.N % 4 == 0 && g.F % 4 == 0 && aligned16(p.A) && aligned16(p.src) && aligned16(p.dst);
   if (vec && ggp_shape_ok(g.F, g.C)) {
@@ -2310,7 +2340,6 @@ static int dot_impl(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target
     p.R = n; p.K = K; p.N = m; p.lda = mat2->size[0];
     p.GX = 1; p.G = 1; p.TX = 1; p.TYX = 1; p.SH = 1; p.SW = 1; p.ssy = 1; p.ssx = 1; p.y0 = 0; p.x0 = 0; p.dir = 1;
     p.DW = 1; p.DP = 1; p.dsy = 1; p.dsx = 1; p.dy0 = 0; p.dx0 = 0;
-    p.nblk = divup(m, 128); p.ncols = p.nblk;
     p.scaleTargets = beta; p.relu = relu;
     if (mask && numel(mask) != numel(target)) return ERROR_INCOMPATIBLE_DIMENSIONS;
     p.mask = mask ? mask->data_device : nullptr; p.post_scale = post_scale;
@@ -2318,9 +2347,10 @@ static int dot_impl(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target
     t_op = t2 ? "fc_fprop" : "fc_dgrad";
     t_flops = 2.0 * m * (double)n * K;
     t_exec = 0.0;
+    p.skinny = m <= 128 && getenv("CONVNET_GG_NO_SKINNY") == nullptr;
     if (t2) {   // NT: A[r=f + F*k=d]
       const bool v = base_vec && n % 4 == 0;
-      if (v && ggp_shape_ok(n, K)) p.KC = K;   // one tap: tap-major IS channel-major, no re-layout
+      if (v && !p.skinny && ggp_shape_ok(n, K)) p.KC = K;   // one tap: tap-major IS channel-major, no re-layout
       gg_run<false>(p, v, (size_t)m * n);
     } else {    // NN: A[k=f + F*r=d]
       gg_run<true>(p, base_vec && K % 4 == 0 && mat2->size[0] % 4 == 0, (size_t)m * n);

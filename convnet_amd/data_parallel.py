@@ -70,12 +70,22 @@ class GradientExchange:
             import ctypes
             from ._lib import lib
             buf = ctypes.create_string_buffer(128)
-            if self.rank_ == 0 and lib.convnet_hip_comm_unique_id(buf) != 0:
-                raise RuntimeError("convnet_hip_comm_unique_id failed")
-            box = [buf.raw]
+            # rank 0's verdict travels WITH the id: a failure there must not leave the other ranks parked in the broadcast
+            ok = self.rank_ != 0 or lib.convnet_hip_comm_unique_id(buf) == 0
+            box = [bool(ok), buf.raw, "" if ok else lib.get_last_cuda_error().decode()]
             dist.broadcast_object_list(box, src=0)
-            if lib.convnet_hip_comm_init(self.rank_, self.world_, box[0]) != 0:
-                raise RuntimeError("convnet_hip_comm_init failed: " + lib.get_last_cuda_error().decode())
+            if not box[0]:
+                raise RuntimeError("convnet_hip_comm_unique_id failed on rank 0: " + box[2])
+            rc = lib.convnet_hip_comm_init(self.rank_, self.world_, box[1])
+            # ... and every rank learns whether EVERY rank got its communicator before anyone posts a collective on it
+            verdicts = [None] * self.world_
+            dist.all_gather_object(verdicts, rc)
+            if any(v != 0 for v in verdicts):
+                if rc == 0:
+                    lib.convnet_hip_comm_destroy()
+                raise RuntimeError(f"convnet_hip_comm_init failed (per-rank return codes {verdicts}): " + lib.get_last_cuda_error().decode())
+            import atexit
+            atexit.register(self.Close)   # never leave a live communicator + stream to interpreter teardown
         self.comm_stream_ = None
         self.net_ = None
         self.bucket_of_ = {}
@@ -84,6 +94,25 @@ class GradientExchange:
         self.done_events_ = {}
         self.ready_count_ = {}
         self.next_slot_ = 0
+        self.closed_ = False
+
+    def Close(self):
+        """Drains and destroys the library's communicator (transport "abi"); idempotent.  The torch process group stays the caller's."""
+        if self.transport_ == "abi" and not self.closed_:
+            from ._lib import lib
+            lib.convnet_hip_comm_sync()
+            lib.convnet_hip_comm_destroy()
+        self.closed_ = True
+
+    def _drain_library_comm(self):
+        """Two communicators live in one process with transport "abi" — the library's (its own non-blocking stream) and torch's.
+        Nothing orders collectives of one against the other, and concurrently running communicators are a known NCCL/RCCL deadlock
+        hazard (ranks can enter the two collectives in different orders).  Every torch collective issued while the library's
+        communicator exists therefore first drains the library's stream on the host: rare calls (one metric sum per step)."""
+        if self.transport_ == "abi" and not self.closed_:
+            from ._lib import lib
+            if lib.convnet_hip_comm_sync() != 0:
+                raise RuntimeError("convnet_hip_comm_sync failed: " + lib.get_last_cuda_error().decode())
 
     def Broadcast(self, mat, src=0):
         """ConvNet::Broadcast (src/convnet.cc:407-413) as one RCCL broadcast of the flat buffer."""
@@ -117,6 +146,12 @@ class GradientExchange:
         slices = [(e, *net.edge_slices_[e]) for e in order]
         self.buckets_ = plan_buckets(slices, self.bucket_bytes_)
         self.bucket_of_ = {e: i for i, b in enumerate(self.buckets_) for e in b}
+        if self.transport_ == "abi":
+            # one slot per merged range per step: checked against the library's table HERE, not half-way through a backward pass
+            from ._lib import lib
+            need, have = sum(len(self._flat_ranges(b)) for b in self.buckets_), lib.convnet_hip_comm_max_slots()
+            if need > have:
+                raise RuntimeError(f"gradient exchange needs {need} slots per step, the library has {have}: raise bucket_bytes")
         if torch.cuda.is_available() and net.grad_parameters_.tensor().is_cuda:
             self.comm_stream_ = torch.cuda.Stream()
 
@@ -157,6 +192,8 @@ class GradientExchange:
                     raise RuntimeError("convnet_hip_comm_allreduce_avg failed: " + lib.get_last_cuda_error().decode())
                 slots.append(slot)
             self.done_events_[i] = _AbiDone(slots)
+            if not self.overlap_:
+                self.done_events_[i].wait_library_stream()   # serial: the compute stream waits for the exchange right here
             return
         flat = self.net_.grad_parameters_.tensor()
         parts = [flat[lo:hi] for lo, hi in self._flat_ranges(self.buckets_[i])]
@@ -185,7 +222,8 @@ class GradientExchange:
     def SumScalars(self, values):
         """ConvNet::Accumulate(train_error, MPITAG_TRAINERROR) (src/convnet.cc:939): the per-rank training-accuracy counts
         summed over ranks for the log line."""
-        dev = "cuda" if self.comm_stream_ is not None else "cpu"
+        self._drain_library_comm()
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"   # the process group's transport decides, not ours
         t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t.tolist()

@@ -8,13 +8,25 @@ import numpy as np
 from .matrix import Matrix
 
 
-_libm = ctypes.CDLL("libm.so.6")
-_libm.expf.restype, _libm.expf.argtypes = ctypes.c_float, [ctypes.c_float]
+_libm = None
 
 
 def _expf(x):
-    """glibc's expf — the function the reference's `exp(float)` resolves to (numpy's float32 exp is a different implementation)."""
-    return np.float32(_libm.expf(float(x)))
+    """The C library's expf — the function the reference's `exp(float)` resolves to (numpy's float32 exp is a different
+    implementation and may differ in the last bit).  libm is located at first use; on a platform without one the float32 numpy
+    value is used."""
+    global _libm
+    if _libm is None:
+        import ctypes.util
+        try:
+            lm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+            lm.expf.restype, lm.expf.argtypes = ctypes.c_float, [ctypes.c_float]
+            _libm = lm
+        except (OSError, AttributeError):
+            _libm = False
+    if _libm:
+        return np.float32(_libm.expf(float(x)))
+    return np.exp(np.float32(x), dtype=np.float32)
 
 
 class Optimizer:

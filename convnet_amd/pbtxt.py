@@ -1,4 +1,4 @@
-"""Protobuf *text-format* reader for the reference's model files (proto/convnet_config.proto).
+"""Protobuf *text-format* reader and writer for the reference's model files (proto/convnet_config.proto).
 
 There is no protoc / libprotobuf in the target image, and the hot path needs only the Model / Layer /
 Edge / Optimizer messages, so this is a small schema-driven reader: unknown fields are an error
@@ -199,3 +199,41 @@ def read(path, cls=Model):
     """ReadPbtxt<T> (src/util.cc:87-102)."""
     with open(path) as f:
         return parse(f.read(), cls)
+
+
+def _fmt(v, default):
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    if isinstance(v, str):
+        # enum identifiers are written bare, strings quoted: an enum field's default is one of its upper-case identifiers
+        if isinstance(default, str) and default and default.isupper():
+            return v
+        return '"' + v.replace("\\", "\\\\").replace('"', '\\"') + '"'
+    if isinstance(v, float):
+        return repr(v)
+    return str(v)
+
+
+def dump(msg, indent=0):
+    """Text format of the explicitly set fields, in schema order (what ``TextFormat::Print`` writes): ``parse(dump(m))`` rebuilds m."""
+    pad, out = "  " * indent, []
+    for name, d in type(msg).FIELDS.items():
+        if name not in msg._set:
+            continue
+        v = msg._set[name]
+        sub = d[1] if isinstance(d, tuple) else d
+        if isinstance(sub, type) and issubclass(sub, Msg):
+            for child in (v if isinstance(v, list) else [v]):
+                out.append(f"{pad}{name} {{\n{dump(child, indent + 1)}{pad}}}\n")
+        elif isinstance(v, list):
+            for x in v:
+                out.append(f"{pad}{name}: {_fmt(x, '')}\n")
+        else:
+            out.append(f"{pad}{name}: {_fmt(v, d)}\n")
+    return "".join(out)
+
+
+def write(path, msg):
+    """WritePbtxt<T> (src/util.cc:104-112)."""
+    with open(path, "w") as f:
+        f.write(dump(msg))

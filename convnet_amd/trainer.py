@@ -112,8 +112,9 @@ class TrainLoopMixin:
             lr_reduce_layer_id = names.index(m.reduce_lr_layer_name)
         if not hasattr(self, "lr_reduce_counter_"):
             self.lr_reduce_counter_ = 0
-        if self.is_root_ and checkpoint and not m.timestamp:
-            self.TimestampModel()                 # src/convnet.cc:875
+        if self.is_root_ and checkpoint:
+            self.TimestampModel()                 # src/convnet.cc:875: every Train() on root gets its own stamp — a resumed
+                                                  # run checkpoints beside the file it was loaded from, never over it
         history = {"train": [], "val": [], "lr_reductions": 0}
         train_error, val_error = None, []
         dont_reduce_lr = 0

@@ -89,9 +89,17 @@ const char* convnet_hip_version(void);
  * are fp32 either way.
  *   1 (default): on the bf16 matrix pipe from EXACT three-way splits x = h + m + l (each term a bf16), six of the nine cross
  *     products per operand pair (hh, hm, mh, hl, lh, mm; the dropped ml, lm, ll are <= 2^-23 of a product), fp32 accumulate in
- *     v_mfma_f32_32x32x16_bf16.  Measured error against double on a K = 3456 reduction: 4.08 x 2^-24 of sum|ab| (max), vs 4.55 x
- *     2^-24 for path 0 on the same data (tools/split_gemm.hip) — accumulation rounding dominates both.  Non-finite inputs: an
- *     infinite operand yields NaN (inf - inf in the split) where path 0 yields inf.
+ *     v_mfma_f32_32x32x16_bf16.  Error against double, measured on the product kernels at the exact conv2 / conv4 / fc6 shapes
+ *     (tests/test_split_arithmetic_gpu.py, profiles/r03_split_arithmetic.txt; unit 2^-24 of sum|ab|): N(0,1) data 4.2-4.7 vs
+ *     4.4-6.1 for path 0 — accumulation rounding dominates both; terms 2^40 apart inside one dot product 14-19 vs 11-14; terms that
+ *     cancel in pairs to 2^-12 (only exact products survive) 0.11 vs 0.05.
+ *     Where path 1 is NOT plain fp32 arithmetic:
+ *       - an ACTIVATION / DERIVATIVE operand with |x| > 3.396e38 (0x7F7F7FFF; the top 0.2 % of the fp32 range, and +-inf) makes
+ *         the outputs it touches NaN (its first split term is a bf16 inf, the residual inf - inf) where path 0 gives +-inf or a
+ *         huge finite number.  NaN operands behave as on path 0.
+ *       - a FILTER / WEIGHT operand above that range (or +-inf) saturates to +-3.3895e38 (bf16 max).
+ *       - operands below ~2^-110 in magnitude: their second / third split terms are denormals, which the matrix pipe flushes;
+ *         the product then carries 8-16 instead of 24 significant bits (measured <= 2^-20 of sum|ab| at |x| ~ 2^-116).
  *   0: v_mfma_f32_32x32x2_f32 (round 1's path; exact fp32 products).
  * Initial value: environment CONVNET_GG_SPLIT (0/1), else 1.  May be changed between calls at any time. */
 void convnet_hip_set_matrix_path(int path);
@@ -340,6 +348,7 @@ int convnet_hip_comm_unique_id(char* id_out);
 int convnet_hip_comm_init(int rank, int nranks, const char* id_in);
 int convnet_hip_comm_rank(void);
 int convnet_hip_comm_size(void);
+int convnet_hip_comm_max_slots(void);   /* slots [0, max_slots) exist (256): plan the posts of one step against it up front */
 int convnet_hip_comm_broadcast(cudamat* mat, int root);
 int convnet_hip_comm_allreduce_avg(cudamat* flat, size_t offset, size_t count, int slot);
 int convnet_hip_comm_wait(int slot);

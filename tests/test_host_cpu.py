@@ -271,3 +271,39 @@ def test_bench_kernel_name_matching_and_one_stream_fields():
     one = b.one_stream_fields(rows, "k")["one_stream"]
     assert one["achieved"] == 200.0 and one["launches"] == 8 and one["avg_launch_ms"] == 0.5 and abs(one["frac"] - 200.0 / 157.3) < 1e-4
     assert b.one_stream_fields(rows, "absent") == {} and b.one_stream_fields(None, "k") == {}
+    # a bf16-split build is priced on the pipe it executes on: 2500 dense bf16 TFLOP/s / 6 MFMA flops per fp32 product — no
+    # fraction on the bench line is taken against the fp32 instruction's peak any more (a fraction that can exceed 1)
+    rows = [{"kernel": "ggp_kernel<2,2,2,128,split,pre>", "ms": 2.0, "flops": 4e11, "launches": 4}]
+    one = b.one_stream_fields(rows, "ggp_kernel<2,2,2,128,split,pre>")["one_stream"]
+    assert abs(one["frac"] - 200.0 / (2500.0 / 6)) < 1e-4 and one["frac"] < 1
+    assert b.kernel_peak("wg_kernel<2,2,2,2,split>") == pytest.approx(416.6667, rel=1e-5) and b.kernel_peak("wg_kernel<2,2,2,2>") == 157.3
+
+
+@pytest.mark.parametrize("gen", ["alexnet", "alexnet_nin", "vgg", "mnist_conv", "lenet5"])
+def test_pbtxt_writer_round_trips_every_model(gen):
+    """WritePbtxt (src/util.cc:104-112) counterpart: the text the writer emits parses back to the same message — explicit presence,
+    repeated fields, nested optimizers, enums bare and strings quoted."""
+    m = pbtxt.parse(getattr(models, gen)())
+    m.timestamp.append("20140621074703")
+    m.checkpoint_dir = 'dir with "quotes"'
+    text = pbtxt.dump(m)
+    back = pbtxt.parse(text)
+    assert pbtxt.dump(back) == text and back.timestamp == ["20140621074703"] and back.checkpoint_dir == 'dir with "quotes"'
+    assert 'activation: RECTIFIED_LINEAR' in text and 'name: "' in text
+    assert [l.name for l in back.layer] == [l.name for l in m.layer] and [(e.source, e.dest) for e in back.edge] == [(e.source, e.dest) for e in m.edge]
+    assert back.edge[0].has_weight_optimizer() == m.edge[0].has_weight_optimizer()
+
+
+def test_timestamp_model_stamps_every_run_and_writes_the_pbtxt(tmp_path):
+    """ConvNet::TimestampModel (src/convnet.cc:830-838): a new stamp per Train() on root (a resumed model keeps its old stamps and
+    gets a new checkpoint name), <dir>/<name>_<stamp>.pbtxt written, log file names set."""
+    net = ConvNet(models.mnist_conv())
+    net.model_.checkpoint_dir = str(tmp_path)
+    first = net.TimestampModel()
+    ck1 = net.GetCheckpointFilename()
+    second = net.TimestampModel()
+    assert net.model_.timestamp == [first, second] and second > first and net.GetCheckpointFilename() != ck1
+    for ts in (first, second):
+        assert os.path.exists(os.path.join(str(tmp_path), f"{net.model_.name}_{ts}.pbtxt"))
+    assert pbtxt.read(os.path.join(str(tmp_path), f"{net.model_.name}_{second}.pbtxt")).timestamp == [first, second]
+    assert net.log_file_.endswith(f"{second}_train.log") and net.val_log_file_.endswith(f"{second}_valid.log")
