@@ -22,10 +22,16 @@ import torch
 import torch.distributed as dist
 
 
-def plan_buckets(slices, bucket_bytes):
+def plan_buckets(slices, bucket_bytes, split_tail=False):
     """slices: list of (key, offset, length) in the order gradients become final (backward order).
     Returns list of buckets, each a list of keys, each bucket contiguous-by-order with >= bucket_bytes
-    (except possibly the last).  Pure function (unit-tested on CPU)."""
+    (except possibly the last).  Pure function (unit-tested on CPU).
+
+    ``split_tail``: the LAST bucket is the one nothing overlaps — its all-reduce and its edges' optimizer steps start only when
+    the first layer's weight gradient is done, at the very end of the step.  With the greedy rule alone that bucket also holds
+    whatever earlier slices did not reach ``bucket_bytes`` (AlexNet at 8 MB: conv3 + conv2 + conv1 = 6 MB and three optimizer steps
+    waiting for conv1's 56 KB).  Splitting the final slice off lets the rest go out one layer earlier, while the first layer's
+    backward still runs; the price is one more small collective."""
     buckets, cur, cur_bytes = [], [], 0
     for key, _, length in slices:
         cur.append(key)
@@ -35,6 +41,9 @@ def plan_buckets(slices, bucket_bytes):
             cur, cur_bytes = [], 0
     if cur:
         buckets.append(cur)
+    if split_tail and buckets and len(buckets[-1]) > 1:
+        last = buckets.pop()
+        buckets += [last[:-1], last[-1:]]
     return buckets
 
 
@@ -65,7 +74,6 @@ class GradientExchange:
         self.bucket_bytes_ = bucket_bytes
         self.overlap_ = overlap
         self.transport_ = transport
-        self.avg_native_ = dist.get_backend() == "nccl"    # gloo has no ReduceOp.AVG (CPU or GPU tensors)
         if transport == "abi":
             import ctypes
             from ._lib import lib
@@ -144,7 +152,7 @@ class GradientExchange:
         if missing:
             raise RuntimeError(f"gradient exchange: edges {missing} own parameters but never complete in backward order")
         slices = [(e, *net.edge_slices_[e]) for e in order]
-        self.buckets_ = plan_buckets(slices, self.bucket_bytes_)
+        self.buckets_ = plan_buckets(slices, self.bucket_bytes_, split_tail=True)
         self.bucket_of_ = {e: i for i, b in enumerate(self.buckets_) for e in b}
         if self.transport_ == "abi":
             # one slot per merged range per step: checked against the library's table HERE, not half-way through a backward pass
@@ -213,11 +221,13 @@ class GradientExchange:
             self.done_events_[i] = None
 
     def _all_reduce_mean(self, t):
-        if self.avg_native_:
-            dist.all_reduce(t, op=dist.ReduceOp.AVG)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            t.div_(self.world_)
+        if self.world_ == 1:
+            return   # the mean over one rank: nothing to send (RCCL would run a 250 MB copy kernel per step; csrc/comm.hip)
+        # sum, then a TRUE division by the rank count — the reference's `data[i] /= num_processes_` (src/convnet.cc:431) and what
+        # the library's own transport does (csrc/comm.hip).  ReduceOp.AVG pre-multiplies every contribution by 1/n instead, which
+        # rounds differently unless n is a power of two: one arithmetic for both transports and every rank count.
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t.div_(self.world_)
 
     def SumScalars(self, values):
         """ConvNet::Accumulate(train_error, MPITAG_TRAINERROR) (src/convnet.cc:939): the per-rank training-accuracy counts

@@ -19,6 +19,12 @@ def test_plan_buckets_orders_and_sizes():
     assert b == [["out", "fc7"], ["fc6"], ["c2", "c1"]]
     assert plan_buckets(slices, 1) == [[k] for k, _, _ in slices]
     assert plan_buckets(slices, 1 << 30) == [[k for k, _, _ in slices]]
+    # the tail rule GradientExchange uses: the last slice (the first layer's gradient, final only when the step ends) travels
+    # alone, so what shared its bucket goes out one layer earlier
+    assert plan_buckets(slices, 4 * 250, split_tail=True) == [["out", "fc7"], ["fc6"], ["c2"], ["c1"]]
+    assert plan_buckets(slices, 1 << 30, split_tail=True) == [["out", "fc7", "fc6", "c2"], ["c1"]]
+    assert plan_buckets(slices, 1, split_tail=True) == [[k] for k, _, _ in slices]
+    assert plan_buckets(slices[:1], 1 << 30, split_tail=True) == [["out"]]
 
 
 def _free_port():
@@ -136,7 +142,7 @@ def test_register_places_a_tied_owner_where_its_last_sharer_completes():
     net.edge_slices_ = {owner: (0, 200), mid: (256, 1000)}
     net.grad_parameters_ = _FakeFlat(torch.zeros(1280))
     ex = GradientExchange.__new__(GradientExchange)
-    ex.bucket_bytes_, ex.comm_stream_ = 1, None
+    ex.bucket_bytes_, ex.comm_stream_, ex.transport_ = 1, None, "torch"
     ex.Register(net)
     assert ex.buckets_ == [[mid], [owner]]
     # owner nearer the output than its sharer: final at the sharer's position (last in backward order)

@@ -212,9 +212,116 @@ def test_one_rank_rccl_overlap_path_is_bit_identical_to_no_exchange(nccl_one_ran
         if transport == "abi" and ex:
             assert _lib.lib.convnet_hip_comm_sync() == 0
         runs.append(net.parameters_.ToNumpy().reshape(-1).copy())
-        if transport == "abi" and ex:
-            assert _lib.lib.convnet_hip_comm_destroy() == 0
+        if ex:
+            if transport == "abi":     # a torch collective while the library's communicator is live: drained first, then legal
+                assert exchange.SumScalars([3.0, 4.5]) == [3.0, 4.5]
+            exchange.Close()           # destroys the library's communicator (idempotent; also registered atexit)
+            exchange.Close()
+            assert _lib.lib.convnet_hip_comm_size() == 1
     assert np.array_equal(runs[1], runs[2]) and not np.array_equal(runs[0][0], runs[2])
+
+
+def test_abi_transport_without_overlap_is_serial_and_slot_plan_is_checked_up_front(nccl_one_rank):
+    """`overlap=False` is honoured by the C-ABI transport (the compute stream waits for each bucket right after posting
+    it), and a bucket plan that needs more slots than the library has is refused at Register, not half-way through a backward pass."""
+    import torch
+    from convnet_amd import _lib
+    from convnet_amd.convnet import ConvNet
+    from convnet_amd.data_parallel import GradientExchange
+    assert _lib.lib.convnet_hip_comm_max_slots() == 256
+    runs = []
+    for overlap in (True, False):
+        ex = GradientExchange(bucket_bytes=2048, overlap=overlap, transport="abi")
+        net = ConvNet(net_text("dag"), fused=True, exchange=ex, overlap_update=False, overlap_wgrad=False)
+        net.SetBatchsize(8)
+        net.SetupDataset(SliceData(net, 8, 0, 1, seed=9, num_batches=2))
+        net.AllocateMemory(False)
+        if runs:
+            net.parameters_.FromNumpy(runs[0][0])
+        p0 = net.parameters_.ToNumpy().reshape(-1).copy()
+        for _ in range(2):
+            net.TrainOneBatch()
+        torch.cuda.synchronize()
+        runs.append((p0, net.parameters_.ToNumpy().reshape(-1).copy()))
+        ex.Close()
+    assert np.array_equal(runs[0][1], runs[1][1])
+
+    class TooMany(GradientExchange):
+        def _flat_ranges(self, bucket):
+            return [(i, i + 1) for i in range(300)]
+    ex = TooMany(bucket_bytes=1 << 30, overlap=True, transport="abi")
+    net = ConvNet(net_text("tiny_alex"), fused=True, exchange=None)
+    net.SetBatchsize(8)
+    net.SetupDataset(SliceData(net, 8, 0, 1, seed=9, num_batches=2))
+    net.AllocateMemory(False)
+    with pytest.raises(RuntimeError, match="slots per step"):
+        ex.Register(net)
+    ex.Close()
+
+
+_CHILD_RCCL = r'''
+import os, sys
+sys.path[:0] = [{here!r}, {root!r}]
+import numpy as np, torch, torch.distributed as dist
+from convnet_amd.convnet import ConvNet
+from convnet_amd.matrix import Matrix
+from convnet_amd.data_parallel import GradientExchange
+from test_data_parallel_gpu import SliceData, net_text
+rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+Matrix.SetupCUDADevice(rank)
+os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+res = {{}}
+p0 = np.load(out + ".p0.npy")
+for transport in ("torch", "abi"):
+    ex = GradientExchange(bucket_bytes=4096, overlap=True, transport=transport)
+    net = ConvNet(net_text("tiny_alex"), fused=True, process_id=rank, num_processes=world, exchange=ex, overlap_update=True, overlap_wgrad=True)
+    net.SetBatchsize(8 // world)
+    net.SetupDataset(SliceData(net, 8, rank, world, seed=7, num_batches=2))
+    net.AllocateMemory(False)
+    net.parameters_.FromNumpy(p0)
+    for _ in range(3):
+        net.TrainOneBatch()
+    sums = ex.SumScalars([float(rank + 1), 10.0])       # a torch collective beside the library's live communicator
+    torch.cuda.synchronize()
+    res[transport] = net.parameters_.ToNumpy().reshape(-1).copy()
+    res[transport + "_sum"] = np.array(sums)
+    ex.Close()
+np.savez(out + f".r{{rank}}.npz", **res)
+dist.destroy_process_group()
+'''
+
+
+def test_two_gpu_rccl_torch_and_abi_transports_are_bitwise_equal(tmp_path):
+    """Needs two GPUs (skipped on the 1-GPU test box): two RCCL ranks, one per GPU, the same run through torch.distributed's
+    all_reduce(AVG) and through the library's convnet_hip_comm_* entries (sum, then a true division by the rank count): parameters
+    after 3 overlapped steps bit-identical across ranks AND across transports; a torch collective (SumScalars) issued while the
+    library's own communicator is live completes (ADVICE r02: two communicators in one process)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs: RCCL refuses two ranks on one device")
+    from convnet_amd import pbtxt
+    from convnet_amd.convnet import ConvNet
+    net = ConvNet(net_text("tiny_alex"))
+    net.SetBatchsize(4)
+    rng = np.random.default_rng(3)
+    out = str(tmp_path / "rccl")
+    # parameter count without touching the GPU in this process: built graph + the reference's slice layout
+    total = sum(((n + 127) // 128) * 128 for n in (e.GetParameterMemoryRequirement() for e in net.edges_) if n)
+    np.save(out + ".p0.npy", (rng.standard_normal(total) * 0.05).astype(np.float32))
+    port = str(_free_port())
+    code = _CHILD_RCCL.format(here=HERE, root=ROOT)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", port, out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    for p in procs:
+        so, se = p.communicate(timeout=300)
+        assert p.returncode == 0, se[-3000:]
+    r0, r1 = np.load(out + ".r0.npz"), np.load(out + ".r1.npz")
+    for t in ("torch", "abi"):
+        assert np.array_equal(r0[t], r1[t]), f"replicas diverged ({t})"
+        assert np.array_equal(r0[t + "_sum"], [3.0, 20.0])
+    assert np.array_equal(r0["torch"], r0["abi"]), "both transports sum, then divide by the rank count: bit for bit"
 
 
 def test_exchange_entries_through_the_c_abi_one_rank():

@@ -71,7 +71,7 @@ def _within(got, want, tol, ulps=4):
     return bool(np.all(d[miss] <= ulps * 2.0 ** -23 * np.maximum(np.abs(a[miss]), np.abs(b[miss]))))
 
 
-def _check_whole_net(net, impl, forced_only=False):
+def _check_whole_net(net, impl, forced_only=False, chain_tol=3e-4):
     """Three comparisons of one training pass with the CPU oracle:
       1. forward chain, un-forced: the oracle sees only the input, the parameters and the device's dropout masks; every layer's
          state within TOL (the softmax output element-wise: its large probabilities dominate a max-over-mean metric);
@@ -84,7 +84,7 @@ def _check_whole_net(net, impl, forced_only=False):
          itself measures the flips, not the kernels (the reference's own GPU and CPU builds differ the same way).  Accumulated
          over the 13 backward ops the bound is CHAIN_TOL."""
     from oracle_net import forward_backward
-    CHAIN_TOL = 3e-4
+    CHAIN_TOL = chain_tol
     x, labels, states, derivs = _train_pass(net)
     t0 = time.time()
     acts, od, og = forward_backward(net, x, labels, impl=impl, force=(states, derivs), dropout_states=states)
@@ -328,3 +328,70 @@ def test_reference_cpu_host_gradient_on_the_full_alexnet_golden(gpu):
             assert l2 < 1e-2, ("gradient samples", e.GetName(), fused, l2)
             nrm = float(np.linalg.norm(g[off:off + n].astype(np.float64)))
             assert abs(nrm - float(G[f"norm_{name}"])) < 2e-3 * float(G[f"norm_{name}"]), ("gradient norm", e.GetName(), fused)
+
+
+# ---- BASELINE configs[4]: the VGG-style 3x3-stacked net, 224x224 ---------------------------------------
+@pytest.mark.parametrize("fused,path", [(True, "split"), (False, "fp32")])
+def test_vgg_224_training_pass_vs_cpu_oracle(gpu, fused, path):
+    """models.vgg() (13 conv 3x3-s1-p1 layers on 224..14-pixel maps, five 2x2-s2 max-pools, 3 FC, dropout on) at 224 x 224, N = 4:
+    every state, every derivative (teacher-forced and end to end with device gates), every dW / db against the CPU oracle —
+    the 224^2 x 64 layers, the 2x2 pool kernels and the many-tile launches only these shapes produce."""
+    from convnet_amd import _lib, models
+    _lib.lib.convnet_hip_set_matrix_path(1 if path == "split" else 0)
+    try:
+        net = _build(models.vgg(), 4, fused)
+        assert net.input_layers_[0].GetSizeY() == 224 and len([e for e in net.edges_ if type(e).__name__ == "ConvEdge"]) == 13
+        # end-to-end bound: 21 backward ops deep instead of AlexNet's 13, the early ones sum 50 176 pixels per weight
+        took = _check_whole_net(net, oracle.port, chain_tol=6e-4)
+        print(f"oracle forward+backward, VGG N=4: {took:.1f} s")
+    finally:
+        _lib.lib.convnet_hip_set_matrix_path(1)
+
+
+@pytest.mark.parametrize("layer", ["conv1_1", "conv1_2"])
+def test_vgg_first_conv_layers_at_full_size_n128(hip, layer):
+    """conv1_1 (3 -> 64) and conv1_2 (64 -> 64), 3x3 s1 p1 on the 224 x 224 map at the benchmark's N = 128 (BASELINE configs[4]):
+    50 176 output pixels x 128 images = 25 088 block tiles per launch; adjointness of the three kernels in float64 and float64
+    spot checks incl. every corner, as for the AlexNet layers."""
+    C = {"conv1_1": 3, "conv1_2": 64}[layer]
+    g = Geom(128, C, 224, 224, 64, 3, 3, 1, 1, 1, 1)
+    rng = np.random.default_rng(C)
+    x = rng.standard_normal(g.in_shape(), dtype=np.float32)
+    w = rng.standard_normal(g.filt_shape(), dtype=np.float32) * np.float32(0.05)
+    dy = rng.standard_normal(g.out_shape(), dtype=np.float32)
+    y = hip.conv_up(g, x, w)
+    dx = hip.conv_down(g, dy, w)
+    dw = hip.conv_outp(g, x, dy)
+    a, b, c = _dot64(y, dy), _dot64(x, dx), _dot64(w, dw)
+    den = max(abs(a), (_dot64(y, y) * _dot64(dy, dy) / y.size) ** 0.5)
+    # (every dW element is a 6.4 M-term fp32 reduction — 50 176 pixels x 128 images — so <w, dW> carries ~1e-4 of accumulation
+    # rounding where the AlexNet layers carry 1e-5; the float64 spot checks below pin individual elements)
+    assert abs(a - b) / den < 3e-5 and abs(a - c) / den < 1.5e-4, (a, b, c)
+    sy_, sdx, sdw = float(np.abs(y).mean()), float(np.abs(dx).mean()), float(np.abs(dw).mean())
+    pts = [(0, 0), (223, 223), (0, 223), (223, 0), (1, 222)] + [(int(rng.integers(224)), int(rng.integers(224))) for _ in range(24)]
+    for (py, px) in pts:
+        n, f, cc = int(rng.integers(g.N)), int(rng.integers(g.F)), int(rng.integers(g.C))
+        assert abs(_ref_up(g, x, w, f, py, px, n) - y[f, py, px, n]) < TOL * sy_, ("fprop", f, py, px, n)
+        assert abs(_ref_down(g, dy, w, cc, py, px, n) - dx[cc, py, px, n]) < TOL * sdx, ("dgrad", cc, py, px, n)
+    for _ in range(4):
+        cc, ky, kx, f = int(rng.integers(g.C)), int(rng.integers(3)), int(rng.integers(3)), int(rng.integers(g.F))
+        assert abs(_ref_outp(g, x, dy, cc, ky, kx, f) - dw[cc, ky, kx, f]) < TOL * sdw, ("wgrad", cc, ky, kx, f)
+
+
+def test_vgg_pool1_2x2_stride2_at_full_size_n128(hip):
+    """pool1 of the VGG net at N = 128: 2x2 windows, stride 2, 64 channels, 224 -> 112; forward bit-exact against numpy, undo routes
+    each gradient to its window's maxima (ties: to every tied element, CPUMatrix.cc / cudamat_conv.cu semantics pinned in
+    test_hip_parity.py) — checked on tie-free random data against the one-hot scatter."""
+    g = Geom(128, 64, 224, 224, 64, 2, 2, 2, 2, 0, 0)
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal(g.in_shape(), dtype=np.float32)
+    y = hip.max_pool(g, x)
+    win = x.reshape(64, 112, 2, 112, 2, 128)
+    want = win.max(axis=(2, 4))
+    assert y.shape == want.shape and np.array_equal(y, want)
+    dy = rng.standard_normal(want.shape, dtype=np.float32)
+    dx = hip.max_pool_undo(g, x, dy, y)
+    hit = win == want[:, :, None, :, None, :]   # (a handful of the 103 M windows tie in float32: every tied element gets the gradient)
+    assert want.size <= hit.sum() < want.size + 100
+    ref = (hit * dy[:, :, None, :, None, :]).reshape(x.shape).astype(np.float32)
+    assert np.array_equal(dx, ref)
