@@ -43,6 +43,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts: see convnet_amd/__init__.py (streams share hardware queues)
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD @ 2.4 GHz
 PEAK_BF16_MATRIX_TFLOPS = 2500.0  # dense v_mfma_f32_32x32x16_bf16: 1024 FLOP/clk/SIMD

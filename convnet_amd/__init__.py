@@ -10,4 +10,14 @@ Layout:
   convnet.py      ConvNet driver (src/convnet.cc): build/sort/alloc, Fprop/Bprop/TrainOneBatch
   data_parallel.py  RCCL gradient exchange (replaces the MPI Accumulate/Broadcast of convnet.cc:407-450)
 """
+import os as _os
+
+# A training step drives up to three HIP streams of its own (compute, weight gradients + optimizer steps, gradient exchange) and
+# RCCL adds its internal ones.  The HIP runtime multiplexes every stream of a process onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4); two streams that land on one queue run strictly one after the other.  Measured on the MI355X with a 1-rank exchange:
+# 12.1 ms per AlexNet step at the default, 11.3 ms with 8 queues (11.1 ms without the exchange) — the "0.7-0.8 ms a 1-rank exchange
+# costs" of round 2 was the second stream sharing a queue with the first.  Must be in the environment before the HIP runtime
+# initialises (the first device call), so it is set at package import; an explicit setting wins.  C/C++ hosts: INTEGRATION.md §4.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 __version__ = "0.1"

@@ -44,6 +44,12 @@ class ConvNet(TrainLoopMixin):
         self.fused = fused
         self.overlap_update_ = bool(overlap_update)
         self.overlap_wgrad_ = bool(overlap_wgrad)
+        # Where a conv edge's weight gradient joins the second stream.  "after": behind the edge's own ComputeDown, so it runs beside
+        # what FOLLOWS the dgrad on the main stream — the previous layer's response-norm / pool undo, which are HBM-bound, instead of
+        # beside the dgrad itself, which wants the same matrix pipe (conv2: dgrad 1.1 ms alone, 2.2 ms beside its own wgrad).
+        # "before" is round 2's order.  CONVNET_WGRAD_ORDER overrides (A/B runs).
+        import os
+        self.wgrad_order_ = os.environ.get("CONVNET_WGRAD_ORDER", "after")
         self.side_stream_ = None
         self._pending_updates = []     # [(edge, event on the main stream after its dgrad, held back?)]
         self._in_train_step = False
@@ -259,9 +265,24 @@ class ConvNet(TrainLoopMixin):
         # owner's slice (edge_with_weight.cc:66-90), so the slice is final only when the last sharing edge has added its part —
         # whichever of them comes last in backward order.
         owner = edge.tied_edge_ if edge.IsTied() else edge
+
+        def dgrad():
+            if input.IsInput():
+                return
+            overwrite = input.AddOrOverwriteDeriv(edge.GetSourceSliceName())
+            if fuse_mask is not None:
+                edge.ComputeDown(output.GetDeriv(), input.GetState(), output.GetState(), input.GetDeriv(), overwrite, fuse_mask=fuse_mask)
+            else:
+                edge.ComputeDown(output.GetDeriv(), input.GetState(), output.GetState(), input.GetDeriv(), overwrite)
+
         if side and self.overlap_wgrad_ and isinstance(edge, EdgeWithWeight):
             # weight gradient on the second stream, behind everything enqueued so far (the derivative it reads); the all-reduce of
-            # a completed slice is posted from that stream too, so its `ready` event covers the wgrad
+            # a completed slice is posted from that stream too, so its `ready` event covers the wgrad.  ComputeOuter reads the
+            # source layer's state and the destination's derivative; ComputeDown writes the SOURCE's derivative: either order of the
+            # two is legal, and nothing later in this step writes what the weight gradient reads.
+            late = self.wgrad_order_ == "after" and isinstance(edge, ConvEdge)
+            if late:
+                dgrad()
             here = torch.cuda.Event()
             here.record(torch.cuda.current_stream())
             self.side_stream_.wait_event(here)
@@ -270,17 +291,14 @@ class ConvNet(TrainLoopMixin):
                 complete = isinstance(owner, EdgeWithWeight) and owner.GetNumGradsReceived() >= owner.num_shares_
                 if self.exchange_ is not None and owner in self.edge_slices_ and complete:
                     self.exchange_.GradReady(owner)
+            if not late:
+                dgrad()
         else:
             edge.ComputeOuter(input.GetState(), output.GetDeriv())
             complete = isinstance(owner, EdgeWithWeight) and owner.GetNumGradsReceived() >= owner.num_shares_
             if self.exchange_ is not None and owner in self.edge_slices_ and complete:
                 self.exchange_.GradReady(owner)     # the slice is final: start its all-reduce
-        if not input.IsInput():
-            overwrite = input.AddOrOverwriteDeriv(edge.GetSourceSliceName())
-            if fuse_mask is not None:
-                edge.ComputeDown(output.GetDeriv(), input.GetState(), output.GetState(), input.GetDeriv(), overwrite, fuse_mask=fuse_mask)
-            else:
-                edge.ComputeDown(output.GetDeriv(), input.GetState(), output.GetState(), input.GetDeriv(), overwrite)
+            dgrad()
         if side and self.overlap_update_ and isinstance(owner, EdgeWithWeight) and complete:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())   # wgrad AND dgrad (which reads the weights) are enqueued
@@ -368,8 +386,8 @@ class ConvNet(TrainLoopMixin):
         import time
         from . import pbtxt
         ts = time.strftime("%Y%m%d%H%M%S")
-        if self.model_.timestamp and ts <= self.model_.timestamp[-1]:   # a resume within the same second must not reuse the name
-            ts = str(int(self.model_.timestamp[-1]) + 1)
+        while ts in self.model_.timestamp:   # a resume within the same second must not reuse the name
+            ts += "_"
         self.model_.timestamp.append(ts)
         fname = os.path.join(self.model_.checkpoint_dir, f"{self.model_.name}_{ts}")
         if self.model_.checkpoint_dir:

