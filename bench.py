@@ -97,6 +97,52 @@ def pmc_traffic(kernel, args):
     return {"traffic": None}
 
 
+def live_pmc_traffic(kernel, args):
+    """`roofline.traffic` measured in THIS run: the same workload, 3 steps, twice more in child processes under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` (separate passes: together the two counters need 5 of the
+    4 TCC slots; --pmc is combined with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes), corrected like
+    tools/pmc_traffic.py (KiB; FETCH_SIZE doubled on gfx950).  After the timed region; rank 0, one GPU only.  None when rocprofv3 is
+    missing or a pass fails — the caller then falls back to the committed passes of the same command."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None or os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None   # no profiler, or this process is itself running under one
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--batch", str(args.batch), "--model", args.model,
+             "--matrix-path", args.matrix_path, "--no-cpu-baseline", "--no-ref-host", "--no-other-path", "--no-kernel-timers", "--no-live-traffic"]
+    child += (["--unfused"] if args.unfused else []) + (["--no-overlap-wgrad"] if args.no_overlap_wgrad else []) + \
+             (["--no-side-stream-update"] if args.no_side_stream_update else [])
+    sums = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
+            paths = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+            if r.returncode != 0 or not paths:
+                return None
+            vals = []
+            with open(paths[0]) as f:
+                for row in csv.DictReader(f):
+                    if row["Counter_Name"] == counter and _same_kernel(kernel, row["Kernel_Name"].split("(")[0].replace("void ", "")):
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            sums[counter] = sum(vals) / len(vals)
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rd, wr = 2 * 1024 * sums["FETCH_SIZE"], 1024 * sums["WRITE_SIZE"]
+    return {"traffic": round(rd + wr), "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, fabric side: Infinity-Cache hits included)",
+            "traffic_read": round(rd), "traffic_write": round(wr),
+            "traffic_source": "measured in this run: two rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE separately) of the same "
+                              "workload, 3 steps each, after the timed region"}
+
+
 def kernel_peak(name):
     """Peak of the pipe a GEMM kernel family executes on, in ALGORITHMIC fp32 TFLOP/s: the bf16-split builds (",split" in the name)
     issue SPLIT_PRODUCTS bf16 MFMA flops per algorithmic flop on the 2.5 PFLOP/s dense bf16 pipe; the others use the fp32 instruction."""
@@ -259,6 +305,9 @@ def main():
                     help="how the GEMM kernels form fp32 products: exact three-way bf16 splits on the bf16 matrix pipe (default) or "
                          "the fp32 matrix instruction (convnet_hip_set_matrix_path)")
     ap.add_argument("--no-other-path", action="store_true", help="skip the second timing with the other matrix path (rank 0, 1 GPU only)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the two rocprofv3 PMC child passes that measure `roofline.traffic` (rank 0, 1 GPU only; ~25 s); the figure "
+                         "is then read from the committed passes under profiles/")
     ap.add_argument("--no-ref-host", action="store_true",
                     help="skip the `ref_host` leg (the reference's own unmodified C++ ConvNet::TrainOneBatch loop linked to this library, "
                          "tools/ref_host_bench.py, timed in a child process after the product run; rank 0, 1 GPU only)")
@@ -415,6 +464,11 @@ def main():
             executed = dom["executed"] / (dom["ms"] * 1e-3) / 1e12
             all_flops = sum(v["flops"] for v in mfma.values())
             all_ms = sum(v["ms"] for v in mfma.values())
+            traffic_fields = None
+            if world == 1 and not args.no_live_traffic:
+                traffic_fields = live_pmc_traffic(dom_name, args)
+            if traffic_fields is None:
+                traffic_fields = pmc_traffic(dom_name, args)
             split_dom = ",split" in dom_name
             peak = kernel_peak(dom_name)
             step_peak = PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS if args.matrix_path == "split" else PEAK_FP32_MATRIX_TFLOPS
@@ -430,7 +484,7 @@ def main():
                 # also counts the MFMA work a dgrad gather spends on border taps that read the zero page
                 "executed": round(executed, 2), "executed_frac": round(executed / peak, 4),
                 "vs_fp32_instruction_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
-                **pmc_traffic(dom_name, args),
+                **traffic_fields,
                 "flops_per_launch": dom["flops"] / dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                 "launches": dom["launches"], "sampled_steps": timed_steps,
                 "all_mfma_kernels": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),

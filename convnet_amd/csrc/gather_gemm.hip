@@ -1265,6 +1265,7 @@ struct WGParams {
   int k_tiles, f_tiles;
   float scaleTargets, scaleOutput;
   int prio;           // issue priority scheme (wg_prio_mode()): 0 none, 1 MFMA phase high, 2 staging phase high
+  int wide;           // the 128 x 128 tile's write-out goes through LDS and leaves as 16-byte stores (F % 4 == 0, 16-byte aligned targets)
 };
 
 constexpr int WG_NB = 32;          // images per stage
@@ -1538,6 +1539,37 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
   const bool fin = p.splits == 1;
   const int KB = p.K + (p.bias_dst ? 1 : 0);
   float* out = fin ? p.dst : p.partial + (size_t)split * KB * p.F;
+  if constexpr (TS == 32 && WM == 2 && WN == 2 && MT == 2 && NTL == 2) {
+    if (p.wide) {
+      // Wide write-out.  The accumulator layout gives a lane ONE filter column and 16 k-rows per tile, so the direct write-out is 64
+      // four-byte stores per lane, 128 contiguous bytes per half-wave.  Each wave transposes its 64 x 64 sub-tile through its quarter
+      // of the (now idle) staging buffers — ds_write_b32 with the lanes along f, ds_read_b128 along f — and stores 16 bytes per lane,
+      // four 256-byte rows per instruction: 16 stores instead of 64.  LDS ops of one wave execute in order: no barrier.  Measured:
+      // fc6 wgrad 157.6 -> 140.0 us at N = 256; at 32 images per GPU (one 32-image chunk of MFMA work per 64 KB tile) the conv and FC
+      // weight-gradient kernels lose 14-15 %.
+      float* ws = smem + wave * 4096;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) ws[(t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh) * 64 + u * 32 + li] = acc[t][u][reg];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int idx = it * 64 + lane, row = idx >> 4, c4 = idx & 15;
+        f32x4 v = ld4(ws + row * 64 + 4 * c4);
+        const int k = kc0 + wm * 64 + row, f = f0 + wn * 64 + 4 * c4;
+        if (k >= KB || f >= p.F) continue;
+        float* dp = (fin && k == p.K) ? p.bias_dst + f : out + (size_t)k * p.F + f;
+        if (fin) {
+          v = v * p.scaleOutput;
+          if (p.scaleTargets != 0.f) v = p.scaleTargets * ld4(dp) + v;
+        }
+        st4(dp, v);
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int u = 0; u < NTL; ++u) {
     const int f = f0 + (wn * NTL + u) * TS + li;
@@ -1965,6 +1997,9 @@ void wg_launch_cfg(WGParams& p, bool vec) {
   p.prio = wg_prio_mode();
   const int tiles = p.k_tiles * p.f_tiles;
   const size_t total = (size_t)(p.K + (p.bias_dst ? 1 : 0)) * p.F;
+  static const bool no_wide = getenv("CONVNET_WG_NO_WIDE") != nullptr;
+  p.wide = (!no_wide && vec && TS == 32 && WM == 2 && WN == 2 && MT == 2 && NTL == 2 && p.F % 4 == 0 && aligned16(p.dst) &&
+            (!p.bias_dst || aligned16(p.bias_dst))) ? 1 : 0;
   // one full round of resident blocks (2 per CU): floor, not ceil — 568 blocks on 512 slots take two
   // rounds and leave the chip half empty (measured: 1.05 waves/SIMD, 46 % MFMA busy).
   int splits = 1;

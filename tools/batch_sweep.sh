@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/sweep_$TAG
 mkdir -p "$O"; cd "$R" || exit 1
 for b in 256 128 64 32; do
-  timeout 200 python bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-ref-host > "$O/bench_b$b.json" 2> "$O/bench_b$b.err"; echo "b=$b rc=$?"
+  timeout 200 python bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-ref-host --no-live-traffic > "$O/bench_b$b.json" 2> "$O/bench_b$b.err"; echo "b=$b rc=$?"
   python - <<PY
 import json
 try:

@@ -13,19 +13,19 @@ echo "== per-layer table"
 timeout 120 python tools/layer_bench.py > "$O/layer_bench.txt" 2>&1; grep -v amdgpu "$O/layer_bench.txt" | head -60
 timeout 120 python tools/pool_bench.py > "$O/pool_bench.txt" 2>&1
 echo "== bench.py data-parallel paths on one rank (RCCL, 1-rank world): torch transport, C-ABI transport, strong-scaling flag"
-timeout 200 python bench.py --force-exchange --steps 8 --warmup 3 --no-cpu-baseline --no-ref-host --no-other-path > "$O/bench_dp1_torch.json" 2> "$O/bench_dp1_torch.err"; echo "rc=$?"; cut -c1-200 "$O/bench_dp1_torch.json"
-timeout 200 python bench.py --force-exchange --transport abi --steps 8 --warmup 3 --no-cpu-baseline --no-ref-host --no-other-path > "$O/bench_dp1_abi.json" 2> "$O/bench_dp1_abi.err"; echo "rc=$?"; cut -c1-200 "$O/bench_dp1_abi.json"
-timeout 200 python bench.py --force-exchange --global-batch 256 --steps 8 --warmup 3 --no-cpu-baseline --no-ref-host --no-other-path > "$O/bench_dp1_strong.json" 2> "$O/bench_dp1_strong.err"; echo "rc=$?"; cut -c300-520 "$O/bench_dp1_strong.json"
+timeout 200 python bench.py --force-exchange --steps 8 --warmup 3 --no-cpu-baseline --no-ref-host --no-other-path --no-live-traffic > "$O/bench_dp1_torch.json" 2> "$O/bench_dp1_torch.err"; echo "rc=$?"; cut -c1-200 "$O/bench_dp1_torch.json"
+timeout 200 python bench.py --force-exchange --transport abi --steps 8 --warmup 3 --no-cpu-baseline --no-ref-host --no-other-path --no-live-traffic > "$O/bench_dp1_abi.json" 2> "$O/bench_dp1_abi.err"; echo "rc=$?"; cut -c1-200 "$O/bench_dp1_abi.json"
+timeout 200 python bench.py --force-exchange --global-batch 256 --steps 8 --warmup 3 --no-cpu-baseline --no-ref-host --no-other-path --no-live-traffic > "$O/bench_dp1_strong.json" 2> "$O/bench_dp1_strong.err"; echo "rc=$?"; cut -c300-520 "$O/bench_dp1_strong.json"
 echo "== other models"
-timeout 200 python bench.py --model vgg --batch 128 --steps 5 --warmup 2 --no-cpu-baseline --no-ref-host --no-other-path > "$O/bench_vgg_bs128.json" 2>/dev/null; cut -c1-200 "$O/bench_vgg_bs128.json"
-timeout 200 python bench.py --model alexnet_nin --steps 10 --warmup 3 --no-cpu-baseline --no-ref-host --no-other-path > "$O/bench_alexnet_nin.json" 2>/dev/null; cut -c1-200 "$O/bench_alexnet_nin.json"
+timeout 200 python bench.py --model vgg --batch 128 --steps 5 --warmup 2 --no-cpu-baseline --no-ref-host --no-other-path --no-live-traffic > "$O/bench_vgg_bs128.json" 2>/dev/null; cut -c1-200 "$O/bench_vgg_bs128.json"
+timeout 200 python bench.py --model alexnet_nin --steps 10 --warmup 3 --no-cpu-baseline --no-ref-host --no-other-path --no-live-traffic > "$O/bench_alexnet_nin.json" 2>/dev/null; cut -c1-200 "$O/bench_alexnet_nin.json"
 echo "== rocprofv3 kernel trace + stats of the bench command"
 cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --stats -d "$O/prof" -o b --output-format csv -- python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-ref-host --no-other-path > "$O/bench_under_rocprof.json" 2> "$O/rocprof.err"; echo "rc=$?"
+timeout 200 rocprofv3 --kernel-trace --stats -d "$O/prof" -o b --output-format csv -- python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-ref-host --no-other-path --no-live-traffic > "$O/bench_under_rocprof.json" 2> "$O/rocprof.err"; echo "rc=$?"
 find "$O/prof" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$O/bench_kernel_stats.csv"; head -12 "$O/bench_kernel_stats.csv" | cut -c1-160
 echo "== PMC traffic passes"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 120 rocprofv3 --kernel-trace --pmc $c -d "$O/pmc_$c" -o p --output-format csv -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-ref-host --no-other-path --no-kernel-timers > "$O/pmc_$c.log" 2>&1
+  timeout 120 rocprofv3 --kernel-trace --pmc $c -d "$O/pmc_$c" -o p --output-format csv -- python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-ref-host --no-other-path --no-live-traffic --no-kernel-timers > "$O/pmc_$c.log" 2>&1
   echo "$c rc=$?"
   find "$O/pmc_$c" -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} "$O/pmc_${c}_counter_collection.csv"
 done
