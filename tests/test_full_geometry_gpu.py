@@ -104,7 +104,9 @@ def _check_whole_net(net, impl, forced_only=False, chain_tol=3e-4):
         if e.GetName() in og:
             dw, db = og[e.GetName()]
             grads[e.GetName()] = (e.GetGradWeight().ToNumpy().reshape(-1), e.GetGradBias().ToNumpy().reshape(-1))
-            assert _within(grads[e.GetName()][0], dw, TOL), ("dW (forced)", e.GetName(), rel_err(grads[e.GetName()][0], dw))
+            # the ulp clause of _within is for FC edges only (fc8's label column at small N); conv edges meet the plain metric
+            ok = _within(grads[e.GetName()][0], dw, TOL) if type(e).__name__ == "FCEdge" else rel_err(grads[e.GetName()][0], dw) < TOL
+            assert ok, ("dW (forced)", e.GetName(), rel_err(grads[e.GetName()][0], dw))
             assert rel_err(grads[e.GetName()][1], db) < TOL, ("db (forced)", e.GetName(), rel_err(grads[e.GetName()][1], db))
     if not forced_only:
         _, ud, ug = forward_backward(net, x, labels, impl=impl, force=(states, None), dropout_states=states)
