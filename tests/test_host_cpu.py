@@ -137,6 +137,46 @@ def test_check_reduce_learning_rate_follows_the_reference_rule():
     assert not net.CheckReduceLearningRate([0.6, 0.6, 0.5, 0.5])                  # an error metric that still falls
 
 
+def test_round3_bench_line_prices_the_dominant_kernel_on_the_pipe_it_executes_on():
+    """profiles/r03_bench_n1.json — the line `python bench.py` printed on the MI355X at the end of round 3: driver contract fields,
+    the roofline against the EXECUTED pipe (2500 dense bf16 TFLOP/s / 6 MFMA flops per fp32 product = 416.67; VERDICT r02 item 4:
+    no fraction may exceed 1), traffic measured live by the two PMC child passes, and the strong-scaling batch sweep beside it."""
+    import json
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    d = json.load(open(os.path.join(root, "r03_bench_n1.json")))
+    for k, t in [("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict),
+                 ("cpu_baseline", dict), ("rccl_ranks", int)]:
+        assert isinstance(d[k], t), k
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["dtype"] == "f32" and d["n_gpus"] == 1 and d["rccl_ranks"] == 0
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3), rel=1e-3)
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["kernel"].endswith(",split,pre>")
+    assert r["peak"] == pytest.approx(2500.0 / 6, abs=0.01) and r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=1e-3)
+    assert r["achieved"] == pytest.approx(r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12, rel=2e-2)
+    assert r["pipe"]["frac"] == pytest.approx(r["frac"], abs=1e-3) and r["pipe"]["peak"] == 2500.0
+    fracs = [r["frac"], r["executed_frac"], r["model_frac"], r["one_stream"]["frac"], r["all_mfma_kernels"]["frac"]] + \
+            [f["frac"] for f in r["families"].values()]
+    assert all(0 < f <= 1 for f in fracs), fracs
+    assert r["one_stream"]["achieved"] > r["achieved"]
+    assert r["traffic"] > 0 and r["traffic_source"].startswith("measured in this run") and r["traffic"] == r["traffic_read"] + r["traffic_write"]
+    # the same kernel's average duration in the rocprofv3 --kernel-trace --stats summary of the same command agrees with the HIP events
+    import csv
+    with open(os.path.join(root, "r03_bench_kernel_stats.csv")) as f:
+        row = next(x for x in csv.DictReader(f) if "ggp_kernel<2, 2, 2, 128, true, true>" in x["Name"])
+    assert float(row["AverageNs"]) * 1e-6 == pytest.approx(r["avg_launch_ms"], rel=0.08)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == "images/sec" and c["sample"]
+    assert d["fp32_mfma_path"]["matrix_path"] == "fp32" and d["fp32_mfma_path"]["value"] < d["value"] and d["fp32_mfma_path"]["model_frac"] < 1
+    assert d["ref_host"]["value"] > 0
+    # per-GPU batches of strong scaling (global 256 over 2 / 4 / 8 GPUs), before and after the flat column space
+    rate = {b: json.load(open(os.path.join(root, f"r03_bench_b{b}.json")))["value"] for b in (128, 64, 32)}
+    before = {b: json.load(open(os.path.join(root, f"r03_before_flat_columns_bench_b{b}.json")))["value"] for b in (128, 64, 32)}
+    assert rate[32] > 1.5 * before[32] and rate[64] > 1.15 * before[64] and rate[128] >= 0.98 * before[128]
+    assert rate[128] > 0.9 * d["value"] and rate[64] > 0.7 * d["value"] and rate[32] > 0.55 * d["value"]
+
+
 @pytest.mark.parametrize("which", ["r01_bench_n1.json", "r02_bench_n1.json", "r02_fp32path_bench_n1.json"])
 def test_committed_bench_line_follows_the_driver_contract(which):
     """profiles/rNN_bench_n1.json is the line `python bench.py` printed on the MI355X: every field the driver and the

@@ -110,8 +110,9 @@ def _data(kind, rng, g):
         return x * np.float32(2.0 ** -116), w * np.float32(2.0 ** 20), dy * np.float32(2.0 ** -116)
     if kind == "huge":
         # magnitudes up to the largest the split carries (3.39e38 rounds to a finite bf16); filters small enough that sums stay finite
-        x = np.clip(x * np.float32(1e38), -BF16_RNE_LIMIT, BF16_RNE_LIMIT)
-        dy = np.clip(dy * np.float32(1e38), -BF16_RNE_LIMIT, BF16_RNE_LIMIT)
+        with np.errstate(over="ignore"):   # the few samples beyond 3.4 sigma overflow to inf and are clipped back
+            x = np.clip(x * np.float32(1e38), -BF16_RNE_LIMIT, BF16_RNE_LIMIT)
+            dy = np.clip(dy * np.float32(1e38), -BF16_RNE_LIMIT, BF16_RNE_LIMIT)
         return x, w * np.float32(2.0 ** -20), dy
     raise ValueError(kind)
 
