@@ -325,7 +325,7 @@ __device__ __forceinline__ bool gg_select_tile(const GGParams& p, const GGClassT
   return true;
 }
 
-// CW = images per wave-column (128: 4 interleaved 32-image MFMA column tiles per wave, ds_read_b128;
+// CW = columns per wave-column — consecutive (pixel, image) columns of the flat column space, GGParams::NP — (128: 4 interleaved 32-column MFMA column tiles per wave, ds_read_b128;
 // 64: 2 tiles, ds_read_b64 — used with MT=3 so a 96-row problem (conv1 fprop, conv2 dgrad) fills its tile).
 // O3 = the 3-blocks-per-CU build (launch bound 3 waves/SIMD + the k-row-major B stage that makes it fit): chosen by the
 // host only for launches with enough tiles to fill >= 2 rounds of 768 slots, where it gains 2-6 %; on ~512-tile launches
@@ -1896,7 +1896,7 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   static const std::string kname_gs = kname_g.substr(0, kname_g.size() - 1) + ",split>";
   const std::string& kname = p.KC > 0 ? (gg_split_mode() ? kname_s : kname_p) : ((vec && gg_split_mode()) ? kname_gs : kname_g);
   {
-    // ggp_kernel leaves out border taps when a tile is one pixel and owns its whole reduction: executed <= algorithmic then
+    // ggp_kernel leaves out the border taps no pixel of the tile has when the block owns its whole reduction: executed <= algorithmic then
     const bool skips = p.KC > 0 && splits == 1;
     KernelTimer timer(kname.c_str(), t_op, t_flops, 0.0, skips ? 0.0 : t_exec);
     if constexpr (!AK && WR == 2 && WC == 2 && MT == 2 && CW == 128) {
