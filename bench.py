@@ -57,7 +57,7 @@ def _same_kernel(bench_name, prof_name):
     def parse(n):
         n = n.replace(" ", "")
         if "<" not in n or ">" not in n[n.index("<"):]:
-            return n, []
+            return n.split("::")[-1], []
         return n[:n.index("<")].split("::")[-1], n[n.index("<") + 1:n.rindex(">")].split(",")
     wb, wa = parse(bench_name)
     fb, fa = parse(prof_name)
