@@ -8,8 +8,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libconvnet_hip.so")
-SOURCES = ["state.hip", "gather_gemm.hip", "pool_norm.hip", "elementwise.hip", "input_staging.hip", "comm.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
+SOURCES = ["state.hip", "gather_gemm.hip", "patch_gemm.hip", "pool_norm.hip", "elementwise.hip", "input_staging.hip", "comm.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-inline-asm"]
+# CONVNET_BUILD_DIAG=1: compile the experiment knobs of csrc/common.h (CHIP_DIAG_KNOB) into the library.  Never set for the product.
+if os.environ.get("CONVNET_BUILD_DIAG"):
+    FLAGS.append("-DCONVNET_DIAG")
 
 
 def _stale(target, deps):
@@ -23,7 +26,7 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
     objdir = os.path.join(HERE, "lib", "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(SRC, "common.h"), os.path.join(HERE, "..", "include", "convnet_hip.h")]
+    headers = [os.path.join(SRC, "common.h"), os.path.join(SRC, "gather_gemm.h"), os.path.join(HERE, "..", "include", "convnet_hip.h")]
     objs, procs = [], []
     for s in SOURCES:
         src = os.path.join(SRC, s)

@@ -16,6 +16,7 @@ hipStream_t stream();
 // than the current capacity (growth synchronises the stream first, so in-flight users stay valid).
 void* workspace(size_t bytes);
 void* workspace_aux(size_t bytes);   // independent second arena (dgrad filter images)
+void* workspace_planes(size_t bytes);   // independent third arena (bf16 planes of a gather-GEMM's source tensor)
 // 256 bytes of device zeros (allocated once): where branch-free kernels point out-of-range loads.
 const float* zero_page();
 // 1: GEMM kernels form fp32 products on the bf16 matrix pipe from exact three-way operand splits (default); 0: fp32 MFMA.
@@ -59,6 +60,21 @@ inline int launch_status() {
   }
   return 0;
 }
+
+// Launcher switches read from the environment ONCE per process.  None of them changes a result: they select between kernels /
+// schedules that compute the same thing (A/B runs).  The product build honours only the documented few (CHIP_KNOB:
+// CONVNET_GG_PATCH, CONVNET_GG_SPLIT); the experiment knobs of earlier rounds exist only in a -DCONVNET_DIAG build and are
+// compile-time constants otherwise.
+inline int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+#define CHIP_KNOB(name, dflt) ([] { static const int v_ = ::chip::env_int(name, dflt); return v_; }())
+#ifdef CONVNET_DIAG
+#define CHIP_DIAG_KNOB(name, dflt) CHIP_KNOB(name, dflt)
+#else
+#define CHIP_DIAG_KNOB(name, dflt) (dflt)
+#endif
 
 inline int divup(int a, int b) { return (a + b - 1) / b; }
 inline size_t numel(const cudamat* m) { return (size_t)m->size[0] * (size_t)m->size[1]; }

@@ -32,298 +32,9 @@
 
 #include "common.h"
 
+#include "gather_gemm.h"
+
 namespace chip {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-constexpr int BK = 16;  // reduction depth per LDS stage (gg_kernel)
-
-// Diagnostic build only (tools/gg_trace.cc compiles this file with -DCONVNET_GG_TRACE; the library never does): per-block phase
-// timing of gg_kernel's main loop with s_memtime — where a chunk's wall time goes (staging issue / MFMA phase / closing wait +
-// barrier), how the two co-resident blocks of a CU share the matrix pipe, and how far block end times spread.
-#ifdef CONVNET_GG_TRACE
-constexpr bool kTrace = CONVNET_GG_TRACE >= 2;          // 2: per-chunk phases (perturbs the loop by ~20 %); 1: block-level times only
-__device__ unsigned long long* g_gg_trace = nullptr;   // 16 words per (block, wave)
-#else
-constexpr bool kTrace = false;
-#endif
-__device__ __forceinline__ unsigned long long trace_clock() {
-#ifdef CONVNET_GG_TRACE
-  return __builtin_amdgcn_s_memtime();
-#else
-  return 0;
-#endif
-}
-
-struct GGParams {
-  const float* A;
-  const float* src;
-  float* dst;
-  const float* bias;  // per output row, nullable
-  float* partial;     // split-K slabs, nullable
-  const float* zero;  // >= 16 bytes of zeros: target of out-of-range loads (branch-free fast path)
-  int R, K, N;
-  int lda;            // A[r + lda*k] (r-contiguous) or A[k + lda*r] (k-contiguous)
-  int GX, G;          // output pixel grid of this launch: G = GY*GX pixels, m = oy*GX + ox
-  int TX, TYX;        // taps: k = ch*TYX + a*TX + b   (channel-major, KC == 0)
-  int ablate;         // ggp_kernel timing diagnostic (CONVNET_GG_ABLATE; results are WRONG): 1 = every staging load reads the zero page
-                      // (address work and LDS-DMA issue kept, no memory traffic), 2 = no staging after the second chunk
-  int apre;           // ggp_kernel split build: A is the pre-split bf16-plane image of the bank (filter_planes_kernel / dgrad_filter_planes_kernel)
-  int KC;             // > 0 (ggp_kernel): reduction order k = ((cb*TYX + tap)*BK + c16, channel ch = cb*BK + c16 of KC — every chunk of BK
-                      // k-rows is ONE tap of one 16-channel block, taps innermost — over a filter bank re-laid to match
-  int SH, SW;         // source image
-  int ssy, ssx, y0, x0, dir;       // source row of tap a: oy*ssy + y0 + dir*a
-  int DW, DP;         // dest image width, pixels per channel (DH*DW)
-  int dsy, dsx, dy0, dx0;          // dest pixel: (oy*dsy + dy0, ox*dsx + dx0)
-  int NP;             // column pitch of one output pixel.  The column space of the GEMM is FLAT: column q = m*NP + n is image n of
-                      // output pixel m, and wave-column `colid` owns columns [colid*CW, colid*CW + CW).  Vector path: NP = N (N % 4 == 0,
-                      // so a 16-byte piece never straddles pixels) — a wave-column spans CW/N pixels when N < CW, and no MFMA column
-                      // is padding at any batch size (round 2 gave every pixel ceil(N/CW) wave-columns of its own: at 32 images per GPU
-                      // three quarters of every MFMA column were zeros).  Scalar path: NP = ceil(N/CW)*CW, the padded form.
-  int ncols;          // ceil(G*NP / CW) wave-columns in total
-  int row_tiles, col_tiles;
-  int chunks_per_split;  // in BK units
-  int splits;
-  size_t slab;        // floats per split slab (= dst extent)
-  float scaleTargets;
-  int relu;
-  const float* mask;  // nullable; same layout as dst: out = mask > 0 ? out * post_scale : 0  (fused ReLU' [+dropout'])
-  float post_scale;
-  // Tail split (tail_splits > 1): tiles [0, tail_first) are whole-K blocks that fill complete rounds of the resident
-  // block slots; the remaining tiles — the partial last round — are each cut into tail_splits K-ranges so the last round
-  // is full too.  Their raw accumulators go to tail_partial in register order and gg_tail_fix_kernel sums them and runs
-  // the normal epilogue.  Block b: XCD k = b & 7 does its run of tail_tf8 full tiles, then its tail_tt8 tail pieces.
-  int tail_first, tail_splits, tail_cps, tail_tf8, tail_tt8;
-  float* tail_partial;
-  int prio;            // issue priority scheme of the main loop (gg_prio_mode())
-  int skinny;          // host only: the whole column space is <= 128 columns (an FC layer at <= 128 images per GPU): gg_run picks the
-                       // 128-row x 64-column tile instead of padding a 256-column one with zeros
-};
-
-// A strided dgrad is one gather-GEMM per stride class (conv_down_impl); the classes differ only in the fields
-// below.  Passing them as a table lets ONE launch cover all classes: block b belongs to the class whose
-// [tile_end[c-1], tile_end[c]) range holds b (classes sorted by K, largest first, so the long blocks are
-// dispatched first and the short ones fill the tail).  n == 0: ordinary single-problem launch.
-struct GGClass {
-  const float* A;
-  int K, GX, G, TX, TYX, y0, x0, dy0, dx0, ncols, col_tiles, tile_end;
-};
-constexpr int kMaxClasses = 16;
-struct GGClassTable {
-  int n;
-  GGClass c[kMaxClasses];
-};
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-
-// compile-time loop: f(integral_constant<int, I>) for I in [B, E) — keeps register-array indices constant
-template <int B, int E, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (B < E) {
-    f(std::integral_constant<int, B>{});
-    static_for<B + 1, E>(f);
-  }
-}
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-
-// XCD-aware block -> tile map: hardware places block b on XCD b%8 (observed; speed only).  Give
-// each XCD a contiguous run of logical tiles, ordered row-tile-fastest, so blocks that share a
-// source-column tile run on one XCD's L2 back to back.
-__device__ __forceinline__ int xcd_remap(int b, int total) {
-  const int per = (total + 7) >> 3;
-  return (b & 7) * per + (b >> 3);
-}
-
-// The write-out of one block tile: accumulate into / overwrite the destination with the fused bias, ReLU and mask
-// options (fin), or store the raw sums into this split's slab.  Shared by gg_kernel and gg_tail_fix_kernel.
-template <int WR, int WC, int MT, int CW, bool VEC>
-__device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT][CW / 32], int row_tile, int col_tile, int split,
-                                            int pncols, int pGX, int pG, int pdy0, int pdx0) {
-  constexpr int NTC = CW / 32;
-  using fvec = __attribute__((ext_vector_type(NTC))) float;
-  constexpr int ROWS = WR * MT * 32;
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int wr = wave / WC, wc = wave % WC;
-  const int li = lane & 31, lh = lane >> 5;
-  const int r0 = row_tile * ROWS;
-  const int N = p.N;
-  const int colid = col_tile * WC + wc;
-  if (colid >= pncols) return;
-  const int q = colid * CW + NTC * li;   // flat column (GGParams::NP)
-  const int m = q / p.NP, n = q - m * p.NP;
-  if (m >= pG || n >= N) return;
-  const int oy = m / pGX, ox = m - oy * pGX;
-  const int dpix = (oy * p.dsy + pdy0) * p.DW + ox * p.dsx + pdx0;
-  float* base = (p.splits > 1 ? p.partial + (size_t)split * p.slab : p.dst) + (size_t)dpix * N + n;
-  const bool fin = p.splits == 1;
-#pragma unroll
-  for (int t = 0; t < MT; ++t) {
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = r0 + wr * MT * 32 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-      if (row >= p.R) continue;
-      fvec v;
-#pragma unroll
-      for (int u = 0; u < NTC; ++u) v[u] = acc[t][u][reg];
-      float* dp = base + (size_t)row * p.DP * N;
-      if (fin) {
-        const float bv = p.bias ? p.bias[row] : 0.f;
-        if (VEC) {
-          if (p.scaleTargets != 0.f) {
-            const fvec o = *reinterpret_cast<const fvec*>(dp);
-            v = p.scaleTargets * o + v;
-          }
-          v = v + bv;
-          if (p.relu) {
-#pragma unroll
-            for (int e = 0; e < NTC; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-          }
-          if (p.mask) {
-            const fvec mk = *reinterpret_cast<const fvec*>(p.mask + (dp - p.dst));
-#pragma unroll
-            for (int e = 0; e < NTC; ++e) v[e] = mk[e] > 0.f ? v[e] * p.post_scale : 0.f;
-          }
-          *reinterpret_cast<fvec*>(dp) = v;
-        } else {
-#pragma unroll
-          for (int e = 0; e < NTC; ++e) {
-            if (n + e < N) {
-              float x = v[e];
-              if (p.scaleTargets != 0.f) x = p.scaleTargets * dp[e] + x;
-              x += bv;
-              if (p.relu) x = x > 0.f ? x : 0.f;
-              if (p.mask) x = p.mask[(dp - p.dst) + e] > 0.f ? x * p.post_scale : 0.f;
-              dp[e] = x;
-            }
-          }
-        }
-      } else {
-        if (VEC) {
-          *reinterpret_cast<fvec*>(dp) = v;
-        } else {
-#pragma unroll
-          for (int e = 0; e < NTC; ++e)
-            if (n + e < N) dp[e] = v[e];
-        }
-      }
-    }
-  }
-}
-
-// -------------------------------------------------------------------------------------------------
-// fp32 products on the bf16 matrix pipe (the default matrix path; convnet_hip_set_matrix_path / CONVNET_GG_SPLIT=0 select the fp32
-// instruction instead): every operand value is split EXACTLY into three bf16
-// terms, x = h + m + l with h = rne8(x), m = rne8(x - h), l = x - h - m (the second residual has at most 8 significant bits), and
-// a*b is accumulated in fp32 as hh + hm + mh + hl + lh + mm by six v_mfma_f32_32x32x16_bf16.  The three dropped cross terms
-// (ml, lm, ll) are below 2^-23 of the product.  tools/split_gemm.hip measures it against double on conv4's reduction length:
-// max error 4.08 x 2^-24 of sum|ab| vs 4.55 x 2^-24 for v_mfma_f32_32x32x2_f32 on the same data — the fp32 accumulation rounding
-// dominates both.  Six 32-cycle instructions replace eight 64-cycle ones per 32 x 32 x 16 block: 2.67x the matrix-pipe rate,
-// paid for with ~5.5 VALU per operand element for the split.
-struct Split8 {
-  u32x4 h, m, l;   // 8 bf16 each: one A or B operand of the MFMA
-};
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
-  typedef float f32x2_t __attribute__((ext_vector_type(2)));
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-  f32x2_t v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
-__device__ __forceinline__ void split8(const float (&x)[8], Split8& s) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float x0 = x[2 * q], x1 = x[2 * q + 1];
-    const unsigned H = pk_bf16(x0, x1);
-    const float r0 = x0 - __uint_as_float(H << 16), r1 = x1 - __uint_as_float(H & 0xffff0000u);
-    const unsigned M = pk_bf16(r0, r1);
-    const float s0 = r0 - __uint_as_float(M << 16), s1 = r1 - __uint_as_float(M & 0xffff0000u);
-    s.h[q] = H;
-    s.m[q] = M;
-    s.l[q] = pk_bf16(s0, s1);
-  }
-}
-// Range of the split.  h = rne8(x) is finite for |x| <= 0x7F7F7FFF (3.396e38); above it — the top 0.2 % of the fp32 range and +-inf —
-// h is a bf16 inf and the residual x - h is NaN.  The in-loop split8 above carries no range check (one more VALU per element in
-// loops that are VALU-limited): such an ACTIVATION / DERIVATIVE value makes the outputs it touches NaN where the fp32 instruction
-// gives +-inf or a huge finite number (documented in include/convnet_hip.h, pinned by tests/test_split_arithmetic_gpu.py).  The
-// FILTER operand is split outside the loops (filter_planes_kernel, dgrad_filter_planes_kernel) and saturates instead: +-inf and
-// above-range finite values enter as +-bf16 max (3.3895e38); NaN stays NaN.
-__device__ __forceinline__ void split8_sat(float (&x)[8], Split8& s) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-    if (fabsf(x[j]) > __uint_as_float(0x7F7F7FFFu)) x[j] = copysignf(__uint_as_float(0x7F7F0000u), x[j]);   // false for NaN
-  split8(x, s);
-}
-__device__ __forceinline__ f32x16 mma_bf16(u32x4 a, u32x4 b, f32x16 c) {
-  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 mma_bf16(u32x4 a, u32x4 b, f32x4 c) {   // 16 x 16 tile, 32 k-slots: lane (li, lh) holds k = 8*lh .. 8*lh + 7
-  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-
-// acc += a*b from the split operands: hh + hm + mh + hl + lh + mm, smallest first.  (Measured with m*l and l*m added — every dropped
-// term then is l*l <= 2^-32 of the product: 13-15 % slower on every layer, same parity results; not kept.)
-template <typename Acc>
-__device__ __forceinline__ Acc split_mac(const Split8& a, const Split8& b, Acc v) {
-  v = mma_bf16(a.m, b.m, v);
-  v = mma_bf16(a.h, b.l, v);
-  v = mma_bf16(a.l, b.h, v);
-  v = mma_bf16(a.h, b.m, v);
-  v = mma_bf16(a.m, b.h, v);
-  v = mma_bf16(a.h, b.h, v);
-  return v;
-}
-
-// Which tile does this block compute, and with which per-class fields?  Shared by gg_kernel and ggp_kernel.
-struct GGTile {
-  const float* A;
-  int K, GX, G, TX, TYX, y0, x0, dy0, dx0, ncols, col_tiles;
-  int L, tsplit;   // logical tile; tsplit >= 0: one K-range of a tail tile
-};
-__device__ __forceinline__ bool gg_select_tile(const GGParams& p, const GGClassTable& ct, GGTile& t) {
-  t.A = p.A; t.K = p.K; t.GX = p.GX; t.G = p.G; t.TX = p.TX; t.TYX = p.TYX; t.y0 = p.y0; t.x0 = p.x0; t.dy0 = p.dy0; t.dx0 = p.dx0;
-  t.ncols = p.ncols; t.col_tiles = p.col_tiles; t.tsplit = -1;
-  if (ct.n > 0) {
-    const int b = blockIdx.x;
-    if (b >= ct.c[ct.n - 1].tile_end) return false;
-    int c = 0;
-    while (b >= ct.c[c].tile_end) ++c;
-    const int cbeg = c > 0 ? ct.c[c - 1].tile_end : 0;
-    {
-      // XCD-aware order inside the class (hardware places block b on XCD b%8): the blocks of this class that land on one XCD
-      // take a CONTIGUOUS run of its logical tiles, so neighbouring pixels — which gather overlapping taps — share one L2.
-      // Without it every XCD saw pixels 8 apart and conv2's dgrad fetched each deriv element once per tap (4.2 GiB for a
-      // 169 MiB tensor, profiles/r01_pmc_traffic_bench.json).  Exact counts, no padding blocks: residue r = i%8 owns
-      // q + (r < m) tiles starting at r*q + min(r, m).
-      const int i = b - cbeg, T = ct.c[c].tile_end - cbeg;
-      const int q = T >> 3, m = T & 7, r = i & 7;
-      t.L = r * q + (r < m ? r : m) + (i >> 3);
-    }
-    const GGClass& k = ct.c[c];
-    t.A = k.A; t.K = k.K; t.GX = k.GX; t.G = k.G; t.TX = k.TX; t.TYX = k.TYX;
-    t.y0 = k.y0; t.x0 = k.x0; t.dy0 = k.dy0; t.dx0 = k.dx0; t.ncols = k.ncols; t.col_tiles = k.col_tiles;
-  } else if (p.tail_splits > 1) {
-    const int k = blockIdx.x & 7, i = blockIdx.x >> 3;
-    if (i < p.tail_tf8) {
-      t.L = k * p.tail_tf8 + i;
-    } else {
-      const int j = k * p.tail_tt8 + (i - p.tail_tf8);
-      if (j >= (p.row_tiles * t.col_tiles - p.tail_first) * p.tail_splits) return false;
-      t.L = p.tail_first + j / p.tail_splits;
-      t.tsplit = j % p.tail_splits;
-    }
-  } else {
-    const int tiles = p.row_tiles * t.col_tiles;
-    const int per = (tiles + 7) >> 3;
-    t.L = xcd_remap(blockIdx.x, tiles);
-    if (t.L >= tiles || (int)blockIdx.x >= per * 8) return false;
-  }
-  return true;
-}
 
 // CW = columns per wave-column — consecutive (pixel, image) columns of the flat column space, GGParams::NP — (128: 4 interleaved 32-column MFMA column tiles per wave, ds_read_b128;
 // 64: 2 tiles, ds_read_b64 — used with MT=3 so a 96-row problem (conv1 fprop, conv2 dgrad) fills its tile).
@@ -789,8 +500,8 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
 // (channel, tap_y, tap_x) is wave-uniform and lives in SGPRs; a lane's (wave-column, image quad) never changes.  Same MFMA order,
 // same epilogue, same tile selection as gg_kernel: results are bit-identical to it.
 // -------------------------------------------------------------------------------------------------
-// APRE (with SPLIT): the A operand arrives ALREADY split — filter_planes_kernel / dgrad_filter_planes_kernel write the re-laid filter bank as bf16 planes
-// [chunk][plane h/m/l][k-group lh][row][8 x bf16 = k-slots j of k-rows 2j + lh], so a lane's A fragment of one plane is ONE ds_read_b128
+// APRE (with SPLIT): the A operand arrives ALREADY split — filter_planes_rt_kernel / dgrad_filter_planes_rt_kernel (patch_gemm.hip) write the re-laid filter
+// bank as bf16 planes [chunk][row tile][plane h/m/l][k-group lh][row][8 x bf16 = k-slots j of k-rows 2j + lh], so a lane's A fragment of one plane is ONE ds_read_b128
 // and a third of the loop's split VALU is gone (the bank is a few MB and is rewritten every call anyway).
 template <int WR, int WC, int MT, int CW, bool SPLIT = false, bool APRE = false>
 __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 || (MT * (CW / 32) == 6 && !APRE))) ? 2 : 3)) void ggp_kernel(const GGParams pin, const GGClassTable ct) {
@@ -890,50 +601,82 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
     }
     const float* const zero = p.zero;
     const float* const src = p.src;
-    const int dir = p.dir, SH = p.SH, SW = p.SW, lda = p.lda, R = p.R, ablate = p.ablate;
+    const int dir = p.dir, SH = p.SH, SW = p.SW, lda = p.lda, R = p.R;
     const unsigned plane_bytes = (unsigned)SH * (unsigned)SW * (unsigned)N * 4u;   // < 2^31 floats per tensor (conv_geo)
     const float* bptr;        // this lane's element of k-row 0 of the next chunk to issue
     unsigned bstride;         // bytes between consecutive k-rows for this lane (0 on the zero page)
+    unsigned bvoff;           // this lane's byte offset inside ONE channel plane of the source (fast path below)
+    bool ball;                // every lane of the wave has the tap: no zero-page lane in this chunk
     auto retap = [&]() __attribute__((always_inline)) {
       const int ys = ys0 + dir * ta, xs = xs0 + dir * tb;
       const bool ok = b_ok && (unsigned)ys < (unsigned)SH && (unsigned)xs < (unsigned)SW;
-      const unsigned off = (unsigned)((cb * BK * SH + ys) * SW + xs) * (unsigned)N + (unsigned)bn;
+      const unsigned poff = (unsigned)(ys * SW + xs) * (unsigned)N + (unsigned)bn;
+      const unsigned off = (unsigned)(cb * BK * SH * SW) * (unsigned)N + poff;
       bptr = ok ? src + off : zero;
       bstride = ok ? plane_bytes : 0u;
+      bvoff = poff * 4u;
+      ball = __builtin_amdgcn_ballot_w64(ok) == ~0ull;
     };
     retap();
-    // A stage: lane-linear [krow][ROWS]; instruction `it` covers 16-byte pieces 64*it .. 64*it+63 of the chunk
-    unsigned a_off[NA];   // byte offset of this lane's piece of instruction `it` from the chunk's first filter row
-    bool a_ok[NA];
+    // A stage: lane-linear [krow][ROWS]; instruction `it` covers 16-byte pieces 64*it .. 64*it+63 of the chunk.
+    // APRE: the planes of a (chunk, row tile) are one contiguous run in the order they take in LDS (filter_planes_rt_kernel), so the
+    // whole stage is ONE wave-uniform base + 16 bytes per lane, M0 rewritten once per four pieces (the instruction's immediate offset
+    // advances source and destination together; rows past R are zeros in the planes).  An LDS-DMA instruction that rewrites M0 and
+    // carries a 64-bit per-lane address costs the issuing wave ~2.7x one that does not (tools/dma_issue).
+    unsigned a_off[APRE ? 1 : NA];   // byte offset of this lane's piece of instruction `it` from the chunk's first filter row
+    bool a_ok[APRE ? 1 : NA];
+    if constexpr (!APRE) {
 #pragma unroll
-    for (int it = 0; it < NA; ++it) {
-      const int idx = lane + 64 * it;
-      if constexpr (APRE) {
-        const int pl = idx / ROWS, row = idx - pl * ROWS;   // pl = plane*2 + k-group; 16 bytes per (pl, row)
-        a_ok[it] = r0 + row < R;
-        a_off[it] = (unsigned)(pl * lda + r0 + row) * 16u;
-      } else {
+      for (int it = 0; it < NA; ++it) {
+        const int idx = lane + 64 * it;
         const int krow = idx / (ROWS / 4), q = idx - krow * (ROWS / 4);
         a_ok[it] = r0 + 4 * q < R;
         a_off[it] = (unsigned)(krow * lda + r0 + 4 * q) * 4u;
       }
     }
-    const char* const abase0 = reinterpret_cast<const char*>(T.A);
-    const size_t a_chunk_bytes = (size_t)lda * (APRE ? 96 : BK * 4);   // one chunk of filter rows; chunk index = cb*TYX + tap
+    const unsigned a_lane = (unsigned)lane * 16u;
+    const char* const abase0 = reinterpret_cast<const char*>(T.A) + (APRE ? (size_t)row_tile * (6 * ROWS * 16) : (size_t)0);
+    const size_t a_chunk_bytes = APRE ? (size_t)p.row_tiles * (6 * ROWS * 16) : (size_t)lda * (BK * 4);   // chunk index = cb*TYX + tap
 
     auto issue = [&](int stage) __attribute__((always_inline)) {
-      const char* const abase = abase0 + a_chunk_bytes * (size_t)(cb * TYX + ta * TX + tb);   // wave-uniform
+      const char* abase = abase0 + a_chunk_bytes * (size_t)(cb * TYX + ta * TX + tb);   // wave-uniform
+      if constexpr (APRE) {
+        const unsigned lda0 = (unsigned)(size_t)(lds_ptr_t)(As + stage * A_STAGE);
 #pragma unroll
-      for (int it = 0; it < NA; ++it) {
-        const float* ap = (a_ok[it] && ablate != 1) ? reinterpret_cast<const float*>(abase + a_off[it]) : zero;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)ap, (lds_ptr_t)(As + stage * A_STAGE + 4 * 64 * it), 16, 0, 0);
+        for (int it = 0; it < NA; it += 4) {
+          if (it + 3 < NA) lds_dma4(a_lane, abase, abase, abase, abase, lda0 + 1024u * it);
+          else
+#pragma unroll
+            for (int j = it; j < NA; ++j) lds_dma1(a_lane, abase + 1024 * (j - it), lda0 + 1024u * j);
+          abase += 4096;
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < NA; ++it) {
+          const float* ap = a_ok[it] ? reinterpret_cast<const float*>(abase + a_off[it]) : zero;
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)ap, (lds_ptr_t)(As + stage * A_STAGE + 4 * 64 * it), 16, 0, 0);
+        }
       }
-      const char* bp = reinterpret_cast<const char*>(ablate == 1 ? zero : bptr);
-      const unsigned bstep = ablate == 1 ? 0u : bstride;
+      if (ball) {
+        // every lane reads real data: k-row `it` is one wave-uniform base (SALU) + this lane's 32-bit offset inside a channel plane,
+        // and M0 is rewritten once per four k-rows — the instruction's immediate offset moves the LDS destination by 1 KB per k-row,
+        // the uniform base absorbs the same 1 KB on the source side.  No VALU, a quarter of the M0 writes.
+        const char* sb = reinterpret_cast<const char*>(src) + (size_t)(cb * BK) * plane_bytes;   // wave-uniform: k-row 0 of the chunk
+        const size_t d1 = (size_t)plane_bytes - 1024;
+        const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(Bs + stage * B_STAGE);
 #pragma unroll
-      for (int it = 0; it < NB; ++it) {
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)bp, (lds_ptr_t)(Bs + stage * B_STAGE + 4 * 64 * it), 16, 0, 0);
-        bp += bstep;
+        for (int it = 0; it < NB; it += 4) {
+          lds_dma4(bvoff, sb, sb + d1, sb + 2 * d1, sb + 3 * d1, lds0 + 1024u * it);
+          sb += 4 * (size_t)plane_bytes;
+        }
+      } else {
+        const char* bp = reinterpret_cast<const char*>(bptr);
+        const unsigned bstep = bstride;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)bp, (lds_ptr_t)(Bs + stage * B_STAGE + 4 * 64 * it), 16, 0, 0);
+          bp += bstep;
+        }
       }
       // next chunk: the next tap of the rectangle for the same 16 channels, then the next channel block.  Taps innermost keeps
       // what neighbouring tiles fetch for tap t+1 one chunk — not one whole tap run — away from what they fetched for tap t.
@@ -955,7 +698,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
     __builtin_amdgcn_s_barrier();
     int fill = 2;   // stage of chunk c + 2
     for (int c = 0; c < nchunks; ++c) {
-      const bool more2 = c + 2 < nchunks && ablate != 2;
+      const bool more2 = c + 2 < nchunks;
       if (more2) issue(fill);
       fill = fill == ST - 1 ? 0 : fill + 1;
       // chunk c+1 must have landed before the consumers are released into it
@@ -1113,28 +856,6 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
   gg_epilogue<WR, WC, MT, CW, true>(p, acc, row_tile, col_tile, split, T.ncols, T.GX, T.G, T.dy0, T.dx0);
 }
 
-// Sums the tail_splits partial tiles of one tail tile in fixed order and applies the normal epilogue.
-template <int WR, int WC, int MT, int CW, bool VEC>
-__global__ __launch_bounds__(WR* WC * 64) void gg_tail_fix_kernel(const GGParams p) {
-  constexpr int NT = WR * WC * 64, NTC = CW / 32, ROWS = WR * MT * 32;
-  using fvec = __attribute__((ext_vector_type(NTC))) float;
-  const int L = p.tail_first + blockIdx.x;
-  const int tid = threadIdx.x;
-  f32x16 acc[MT][NTC];
-  const float* pp = p.tail_partial + (size_t)blockIdx.x * p.tail_splits * (size_t)(ROWS * WC * CW);
-#pragma unroll
-  for (int t = 0; t < MT; ++t)
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      fvec v = *reinterpret_cast<const fvec*>(pp + ((size_t)(t * 16 + reg) * NT + tid) * NTC);
-      for (int sp = 1; sp < p.tail_splits; ++sp)
-        v += *reinterpret_cast<const fvec*>(pp + (size_t)sp * (ROWS * WC * CW) + ((size_t)(t * 16 + reg) * NT + tid) * NTC);
-#pragma unroll
-      for (int u = 0; u < NTC; ++u) acc[t][u][reg] = v[u];
-    }
-  gg_epilogue<WR, WC, MT, CW, VEC>(p, acc, L % p.row_tiles, L / p.row_tiles, 0, p.ncols, p.GX, p.G, p.dy0, p.dx0);
-}
-
 // dst = scaleTargets*dst + sum_s slab[s]  (+bias[row], relu) over a full dst extent.
 __global__ void gg_reduce_kernel(float* __restrict__ dst, const float* __restrict__ partial, const float* __restrict__ bias,
                                  size_t total, size_t slab, int splits, size_t per_row, float scaleTargets, int relu,
@@ -1190,55 +911,6 @@ __global__ void filter_tapmajor_kernel(const float* __restrict__ W, float* __res
     const int tap = r % TYX;
     const int c = (int)(r / TYX) * 16 + c16;
     Wt[i] = W[(size_t)f + (size_t)F * (tap + (size_t)TYX * c)];
-  }
-}
-
-// A operand of ggp_kernel<…, SPLIT, APRE>: bf16 planes of the re-laid bank, R rows per k-row, 16 k-rows per chunk:
-// out[(((chunk*3 + plane)*2 + lh)*R + row)*8 + j] = plane(h/m/l) of bank(row, k-row 2j + lh of the chunk)  (exact split, Split8).
-// The two re-layouts and the split in one pass each (what conv_up_impl / conv_down_impl launch on the pre-split path): thread =
-// (chunk, k-group lh, row); its 8 k-slots j are the chunk's k-rows 2j + lh.
-// forward bank: rows f, chunk = tap + TYX*cb, k-row = channel 16*cb + (2j + lh)
-__global__ void filter_planes_kernel(const float* __restrict__ W, u32x4* __restrict__ out, int F, int C, int TYX) {
-  const size_t total = (size_t)(C / 16) * TYX * 2 * F;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int f = (int)(i % F);
-    const size_t r = i / F;
-    const int lh = (int)(r & 1);
-    const size_t chunk = r >> 1;
-    const int tap = (int)(chunk % TYX), cb = (int)(chunk / TYX);
-    float x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = W[(size_t)f + (size_t)F * (tap + (size_t)TYX * (16 * cb + 2 * j + lh))];
-    Split8 sp;
-    split8_sat(x, sp);
-    u32x4* o = out + ((chunk * 3) * 2 + lh) * (size_t)F + f;
-    o[0] = sp.h;
-    o[2 * (size_t)F] = sp.m;
-    o[4 * (size_t)F] = sp.l;
-  }
-}
-// one stride class of the input-gradient bank: rows c, chunk = tap + TYXc*fb, k-row = filter 16*fb + (2j + lh)
-__global__ void dgrad_filter_planes_kernel(const float* __restrict__ W, u32x4* __restrict__ out, int F, int C, int Ky, int Kx, int cy, int cx,
-                                           int sy, int sx, int TYc, int TXc) {
-  const int TYXc = TYc * TXc;
-  const size_t total = (size_t)(F / 16) * TYXc * 2 * C;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const size_t r = i / C;
-    const int lh = (int)(r & 1);
-    const size_t chunk = r >> 1;
-    const int tap = (int)(chunk % TYXc), fb = (int)(chunk / TYXc);
-    const int a = tap / TXc, b = tap - a * TXc;
-    const float* wp = W + (size_t)F * ((cx + sx * b) + Kx * ((cy + sy * a) + (size_t)Ky * c)) + 16 * fb + lh;
-    float x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = wp[2 * j];
-    Split8 sp;
-    split8_sat(x, sp);
-    u32x4* o = out + ((chunk * 3) * 2 + lh) * (size_t)C + c;
-    o[0] = sp.h;
-    o[2 * (size_t)C] = sp.m;
-    o[4 * (size_t)C] = sp.l;
   }
 }
 
@@ -1686,19 +1358,13 @@ double t_exec = 0.0;   // MFMA work the launch issues when it differs from the a
 // raising the STAGING phase (2) beats raising the MFMA phase (1, round 1's choice) and no priority (0) by ~1 % — the co-resident
 // wave's address arithmetic and LDS-DMA issue finish sooner and its MFMA phase starts earlier.
 inline int gg_prio_mode() {
-  static const int v = [] { const char* e = getenv("CONVNET_GG_PRIO"); return e && *e ? atoi(e) : 2; }();
-  return v;
+  return CHIP_DIAG_KNOB("CONVNET_GG_PRIO", 2);
 }
 
 // The producer-wave build of the gather-GEMM (ggp_kernel) for the launches that have one (r-contiguous A, vector path,
 // 64 pieces per k-row).  On by default; CONVNET_GG_PRODUCER=0 restores gg_kernel everywhere (A/B runs).
-inline int gg_ablate_mode() {
-  static const int v = [] { const char* e = getenv("CONVNET_GG_ABLATE"); return e && *e ? atoi(e) : 0; }();
-  return v;
-}
 inline bool gg_producer_mode() {
-  static const bool v = [] { const char* e = getenv("CONVNET_GG_PRODUCER"); return e && *e ? atoi(e) != 0 : true; }();
-  return v;
+  return CHIP_DIAG_KNOB("CONVNET_GG_PRODUCER", 1) != 0;
 }
 
 // Which matrix instruction the GEMM kernels form their products with (matrix_path(), csrc/state.hip): 1 = bf16-split (default;
@@ -1706,25 +1372,24 @@ inline bool gg_producer_mode() {
 // at run time (tests and bench.py run both); CONVNET_WG_SPLIT overrides it for wg_kernel alone (A/B runs).
 inline bool gg_split_mode() { return matrix_path() != 0; }
 inline bool wg_split_mode() {
-  static const int v = [] { const char* e = getenv("CONVNET_WG_SPLIT"); return e && *e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  const int v = CHIP_DIAG_KNOB("CONVNET_WG_SPLIT", -1);
   return v < 0 ? gg_split_mode() : v != 0;
 }
 
 // ggp_kernel exists for the tile shapes whose B stage has 64 sixteen-byte pieces per k-row (gg_run picks those for R > 32).
-inline bool ggp_shape_ok(int R, int KC) { return gg_producer_mode() && R > 32 && KC > 0 && KC % BK == 0 && getenv("CONVNET_GG_ROWS64") == nullptr; }
+inline bool ggp_shape_ok(int R, int KC) { return gg_producer_mode() && R > 32 && KC > 0 && KC % BK == 0 && !CHIP_DIAG_KNOB("CONVNET_GG_ROWS64", 0); }
 
 template <typename Kern>
 int resident_slots(Kern kern, int threads, size_t lds) {
   int n = 0;
   CHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), threads, lds));
   if (n < 1) n = 1;
-  if (getenv("CONVNET_GG_VERBOSE")) fprintf(stderr, "libconvnet_hip: %d resident blocks per CU (%d threads, %zu B LDS)\n", n, threads, lds);
+  if (CHIP_DIAG_KNOB("CONVNET_GG_VERBOSE", 0)) fprintf(stderr, "libconvnet_hip: %d resident blocks per CU (%d threads, %zu B LDS)\n", n, threads, lds);
   return n * 256;   // 256 CUs
 }
 
 inline int wg_prio_mode() {
-  static const int v = [] { const char* e = getenv("CONVNET_WG_PRIO"); return e && *e ? atoi(e) : 2; }();
-  return v;
+  return CHIP_DIAG_KNOB("CONVNET_WG_PRIO", 2);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1750,7 +1415,6 @@ void gg_launch_classes(GGParams& p, GGClassTable& ct, bool vec) {
   p.row_tiles = divup(p.R, ROWS);
   p.zero = zero_page();
   p.prio = gg_prio_mode();
-  p.ablate = gg_ablate_mode();
   p.splits = 1;
   p.chunks_per_split = 1 << 24;
   p.partial = nullptr;
@@ -1808,18 +1472,17 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   p.NP = vec ? p.N : divup(p.N, CW) * CW;
   p.ncols = divup(p.G * p.NP, CW);
   // CONVNET_GG_LDS_PAD (diagnostic): extra dynamic LDS per block, e.g. 65536 to force ONE resident block per CU
-  static const size_t lds_pad = [] { const char* e = getenv("CONVNET_GG_LDS_PAD"); return e && *e ? (size_t)atol(e) : (size_t)0; }();
+  const size_t lds_pad = (size_t)CHIP_DIAG_KNOB("CONVNET_GG_LDS_PAD", 0);
   const size_t lds = sizeof(float) * 2 * (A_STAGE + B_STAGE) + lds_pad;
   p.row_tiles = divup(p.R, ROWS);
   p.col_tiles = divup(p.ncols, WC);
   p.zero = zero_page();
   p.prio = gg_prio_mode();
-  p.ablate = gg_ablate_mode();
   const int tiles = p.row_tiles * p.col_tiles;
   const int kchunks = divup(p.K, BK);
   // 3 blocks per CU (768 slots) for launches with at least two such rounds of tiles; only the 128-row r-contiguous
   // vector build has the variant (it is the one whose register count sits between the 2- and 3-block limits).
-  static const bool no_o3 = getenv("CONVNET_GG_NO_O3") != nullptr;
+  const bool no_o3 = CHIP_DIAG_KNOB("CONVNET_GG_NO_O3", 0) != 0;
   const bool o3 = !no_o3 && !gg_split_mode() && vec && !AK && WR == 2 && WC == 2 && MT == 2 && CW == 128 && tiles >= 2 * 768 && p.KC == 0;
   int slots_launch = o3 ? 768 : kTargetBlocks;
   if constexpr (!AK && WC * (CW / 4) == 64) {
@@ -1863,7 +1526,7 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   p.tail_splits = 1;
   p.tail_partial = nullptr;
   const int slots = slots_launch;
-  static const bool no_tail = getenv("CONVNET_GG_NO_TAIL_SPLIT") != nullptr;
+  const bool no_tail = CHIP_DIAG_KNOB("CONVNET_GG_NO_TAIL_SPLIT", 0) != 0;
   if (!no_tail && splits == 1 && dst_elems > 0 && tiles > slots && tiles % slots != 0 && kchunks >= 32) {
     const int full = (tiles / slots) * slots, rem = tiles - full;
     const double tile_bytes = sizeof(float) * (double)ROWS * WC * CW;
@@ -1951,6 +1614,18 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   }
 }
 
+}  // namespace
+
+void gg_reduce_launch(const GGParams& p, size_t dst_elems, int splits, const char* op) {
+  KernelTimer timer("gg_reduce_kernel", op, 0.0, sizeof(float) * (double)dst_elems * (splits + 1));
+  size_t nb = (dst_elems + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(gg_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream(), p.dst, p.partial, p.bias, dst_elems, p.slab, splits,
+                     (size_t)p.DP * p.N, p.scaleTargets, p.relu, p.mask, p.post_scale);
+}
+
+namespace {
+
 template <bool AK>
 void gg_run(GGParams& p, bool vec, size_t dst_elems) {
   // pick the row tile (128/64/32) that pads the fewest rows; ties go to the larger tile.  (The 96-row
@@ -1958,8 +1633,8 @@ void gg_run(GGParams& p, bool vec, size_t dst_elems) {
   // conv2 dgrad — run 25 % padded on the 128-row kernel: 80 effective TFLOP/s.)
   // row tile by problem height: 128 rows (2x2 waves of 64x128), 96 rows (4 waves of 96x64: conv1 fprop,
   // conv2 dgrad), 64 and 32 rows for small layers.
-  static const int force64 = getenv("CONVNET_GG_ROWS64") ? 1 : 0;   // experiment knob: 64-row tiles everywhere
-  static const bool no_skinny = getenv("CONVNET_GG_NO_SKINNY") != nullptr;
+  const int force64 = CHIP_DIAG_KNOB("CONVNET_GG_ROWS64", 0);   // experiment knob: 64-row tiles everywhere
+  const bool no_skinny = CHIP_DIAG_KNOB("CONVNET_GG_NO_SKINNY", 0) != 0;
   // An FC layer at a small per-GPU batch (strong scaling of a global batch: 128 / 64 / 32 images per GPU) is a GEMM with <= 128
   // columns, bound by streaming the weight matrix once: four waves stacked along the rows, one 64-column wave-column, so a
   // 32-image batch pads 2x instead of 8x and every weight row still reaches LDS with 16-byte pieces.
@@ -1997,7 +1672,7 @@ void wg_launch_cfg(WGParams& p, bool vec) {
   p.prio = wg_prio_mode();
   const int tiles = p.k_tiles * p.f_tiles;
   const size_t total = (size_t)(p.K + (p.bias_dst ? 1 : 0)) * p.F;
-  static const bool no_wide = getenv("CONVNET_WG_NO_WIDE") != nullptr;
+  const bool no_wide = CHIP_DIAG_KNOB("CONVNET_WG_NO_WIDE", 0) != 0;
   p.wide = (!no_wide && vec && TS == 32 && WM == 2 && WN == 2 && MT == 2 && NTL == 2 && p.F % 4 == 0 && aligned16(p.dst) &&
             (!p.bias_dst || aligned16(p.bias_dst))) ? 1 : 0;
   // one full round of resident blocks (2 per CU): floor, not ceil — 568 blocks on 512 slots take two
@@ -2100,9 +1775,12 @@ ConvGeo conv_geo(const Shape4D* img, const Shape4D* flt, const Shape4D* out, con
   return g;
 }
 
+// Row-tile height gg_run / gg_run_classes pick for an R-row problem on the producer-wave kernels (the pre-split filter planes are laid
+// out per row tile of this height, filter_planes_rt_kernel).
+inline int gg_tile_rows(int R) { return CHIP_DIAG_KNOB("CONVNET_GG_ROWS64", 0) ? 64 : R > 96 ? 128 : R > 64 ? 96 : R > 32 ? 64 : 32; }
+
 inline bool gg_presplit_mode() {
-  static const bool off = getenv("CONVNET_GG_NO_PRESPLIT") != nullptr;
-  return gg_split_mode() && !off;
+  return gg_split_mode() && !CHIP_DIAG_KNOB("CONVNET_GG_NO_PRESPLIT", 0);
 }
 
 void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* targets, Shape4D* is, Shape4D* fs, Shape4D* ts,
@@ -2117,19 +1795,29 @@ void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* tar
   p.DW = g.Mx; p.DP = g.My * g.Mx; p.dsy = 1; p.dsx = 1; p.dy0 = 0; p.dx0 = 0;
   p.scaleTargets = scaleTargets; p.relu = relu;
   const bool vec = g.N % 4 == 0 && g.F % 4 == 0 && aligned16(p.A) && aligned16(p.src) && aligned16(p.dst);
+  if (vec && ggp_shape_ok(g.F, g.C) && gg_presplit_mode()) {
+    // patch-resident gather on pre-split source planes (patch_gemm.hip) where the geometry has one
+    p.KC = g.C;
+    if (patch_shape_ok(p)) {
+      t_op = "conv_fprop";
+      t_flops = 2.0 * g.N * p.G * (double)g.F * p.K;
+      const PatchBank bank{filters->data_device, g.F, g.C, g.Ky, g.Kx, 0, 0, 1, 1, g.Ky, g.Kx, false};
+      patch_run(p, (size_t)g.N * p.DP * g.F, t_op, t_flops, bank);
+      note_kernel("gpp_kernel(fprop)", t_flops, p.row_tiles * p.col_tiles, p.splits);
+      return;
+    }
+    p.KC = 0;
+  }
   if (vec && ggp_shape_ok(g.F, g.C)) {
     // producer-wave kernel: the reduction runs tap-major over a re-laid copy of the filter bank (a few MB, ~5 us)
     const size_t welems = (size_t)g.F * p.K;
     if (gg_presplit_mode()) {
       // the consumers read the bank as ready-made bf16 planes: tap-major re-layout and exact three-way split in one pass
-      float* planes = static_cast<float*>(workspace_aux(sizeof(float) * (welems + welems / 2)));
-      const size_t work = (size_t)(g.C / 16) * p.TYX * 2 * g.F;
-      int nb = (int)((work + 255) / 256);
-      if (nb > 2048) nb = 2048;
-      KernelTimer timer("filter_planes_kernel", "conv_fprop", 0.0, 10.0 * welems);
-      hipLaunchKernelGGL(filter_planes_kernel, dim3(nb), dim3(256), 0, stream(), filters->data_device, reinterpret_cast<u32x4*>(planes), g.F, g.C,
-                         p.TYX);
-      p.A = planes;
+      const int TH = gg_tile_rows(g.F);
+      void* planes = workspace_aux((size_t)96 * (g.C / 16) * p.TYX * divup(g.F, TH) * TH);
+      const PatchBank bank{filters->data_device, g.F, g.C, g.Ky, g.Kx, 0, 0, 1, 1, g.Ky, g.Kx, false};
+      filter_planes_rt_launch(bank, planes, p.TYX, TH, "conv_fprop");
+      p.A = static_cast<const float*>(planes);
       p.apre = 1;
     } else if (p.TYX > 1) {
       float* wt = static_cast<float*>(workspace_aux(sizeof(float) * welems));
@@ -2184,10 +1872,15 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
   // one launch per stride class (cy,cx): input rows iy with (iy - pad) % sy == cy share the tap set
   // ky = cy + sy*a; their sources are oy = (iy - pad - cy)/sy - a  (pad = ConvDesc padding, <= 0).
   const size_t wt_floats = ((size_t)g.C * g.F * g.Ky * g.Kx + 64 * (size_t)g.sy * g.sx + 63) / 64 * 64;
-  float* wt = static_cast<float*>(workspace_aux(sizeof(float) * (wt_floats + wt_floats + wt_floats / 2)));   // + room for the bf16 planes
+  // + room for the class banks as bf16 planes per row tile (rows padded to the tile height): 24 floats per (16 filters, tap, row)
+  const int TH = gg_tile_rows(g.C);
+  const size_t pl_floats = (size_t)24 * (g.F / 16 + 1) * g.Ky * g.Kx * divup(g.C, TH) * TH + 64 * (size_t)g.sy * g.sx;
+  float* wt = static_cast<float*>(workspace_aux(sizeof(float) * (wt_floats + pl_floats)));
+  size_t poff = 0;
   size_t woff = 0;
   double flops = 0;
   int blocks = 0;
+  bool patched = false;
   GGParams base{};
   base.src = derivs->data_device; base.dst = targets->data_device; base.bias = nullptr;
   base.R = g.C; base.N = g.N; base.lda = g.C;
@@ -2237,15 +1930,29 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
       woff += (welems + 63) / 64 * 64;
       GGClass k{};
       k.A = wc; k.K = g.F * TYc * TXc;
+      if (!multi && pre && welems > 0) {
+        // a stride-1 convolution: one class, a stride-1 gather over the derivatives -> the patch-resident kernel where it applies
+        GGParams p = base;
+        p.K = k.K; p.GX = GX; p.G = GY * GX; p.TX = TXc; p.TYX = TYc * TXc;
+        p.y0 = jy0; p.x0 = jx0; p.dy0 = iy0; p.dx0 = ix0;
+        if (patch_shape_ok(p)) {
+          const double cflops = 2.0 * g.N * p.G * (double)g.C * p.K;
+          flops += cflops;
+          t_flops = exec_total > 0 ? alg_flops * (cflops / exec_total) : 0.0;
+          const bool whole = g.sy == 1 && g.sx == 1 && GY == g.H && GX == g.W;
+          const PatchBank bank{filters->data_device, g.F, g.C, g.Ky, g.Kx, cy, cx, g.sy, g.sx, TYc, TXc, true};
+          patch_run(p, whole ? (size_t)g.N * g.H * g.W * g.C : 0, t_op, t_flops, bank);
+          patched = true;
+          blocks += p.row_tiles * p.col_tiles;
+          continue;
+        }
+      }
       if (pre && welems > 0) {
         // class bank straight to bf16 planes (re-layout + exact split in one pass)
-        float* pc = planes + (size_t)(wc - wt) / 2 * 3;
-        const size_t work = (size_t)(g.F / 16) * TYc * TXc * 2 * g.C;
-        int nb = (int)((work + 255) / 256);
-        if (nb > 2048) nb = 2048;
-        KernelTimer timer("dgrad_filter_planes_kernel", "conv_dgrad", 0.0, 10.0 * welems);
-        hipLaunchKernelGGL(dgrad_filter_planes_kernel, dim3(nb), dim3(256), 0, stream(), filters->data_device, reinterpret_cast<u32x4*>(pc), g.F,
-                           g.C, g.Ky, g.Kx, cy, cx, g.sy, g.sx, TYc, TXc);
+        float* pc = planes + poff;
+        poff += ((size_t)24 * (g.F / 16) * TYc * TXc * divup(g.C, TH) * TH + 63) / 64 * 64;
+        const PatchBank bank{filters->data_device, g.F, g.C, g.Ky, g.Kx, cy, cx, g.sy, g.sx, TYc, TXc, true};
+        filter_planes_rt_launch(bank, pc, TYc * TXc, TH, "conv_dgrad");
         k.A = pc;
       } else if (welems > 0) {
         int nb = (int)((welems + 255) / 256);
@@ -2279,7 +1986,7 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
     gg_run_classes(base, ct, vec);
     blocks = ct.c[ct.n - 1].tile_end;
   }
-  note_kernel("gg_kernel(dgrad)", alg_flops, blocks, 1);
+  note_kernel(patched ? "gpp_kernel(dgrad)" : "gg_kernel(dgrad)", alg_flops, blocks, 1);
 }
 
 void convDownGemm(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* ds, Shape4D* fs, Shape4D* ts, ConvDesc d,

@@ -1,0 +1,770 @@
+// gpp_kernel: the patch-resident, pre-split gather-GEMM for the 3x3 / 5x5 convolutions (conv_edge fprop and dgrad; the reference
+// lowers both to im2col + cublasSgemm, cudamat_conv_gemm.cu:545-680 / 682-825, and its direct kernels re-read every image pixel
+// per neighbouring module, cudamat_conv_filteracts.cu:985-1140).
+//
+// ggp_kernel (gather_gemm.hip) gives a block ONE output pixel x 256 images, so every (tap, 16-channel chunk) is a fresh 16 KB
+// fetch of raw fp32 source through the CU's vector-memory path, split into bf16 terms by every consumer wave that touches it.
+// Here both are gone:
+//   * the block tile is kPatchP = 4 neighbouring output pixels x 64 images.  For one tap ROW and one 16-channel block the source
+//     pixels the tile needs for ALL taps of that row ("slab": P + taps - 1 pixels, 6 for a 3x3) are staged once; tap b of pixel j
+//     reads slot S(j) + b, a shifted LDS address, not a new load.  A 3x3 row costs 6 slots for 12 pixel-taps;
+//   * the source arrives ALREADY split: act_planes_kernel writes every activation / derivative tensor once as bf16 planes
+//     [plane h/m/l][channel block][k-group][y][x][image] (8 bf16 = 16 bytes per (pixel, image): one MFMA B operand), exactly as
+//     filter_planes_kernel does for the filter bank.  Consumers run ds_read_b128 + MFMA + one barrier per chunk, no VALU.
+// Structure as ggp_kernel: four consumer waves (2 x 2, 64 rows x 128 columns each) + one producer wave that owns all staging: A
+// planes of chunk c+2 into a three-stage ring, the next slab into the idle half of a double buffer, spread over the current
+// slab's chunks; every piece is 1 KB = one slot of one (plane, k-group) = one wave-uniform source address + 16 bytes per lane.
+// Units: the column space is (64-image block, pixel) units in flat order (GGParams::patch); a tile is 4 consecutive units, so it may
+// wrap from one image row to the next (or from one image block to the next): the slot base S(j) then jumps by 3 and the slab needs 8
+// slots instead of 6.  Out-of-image slots are zero-filled by the producer (LDS stores, no memory traffic); slots no pixel reads are
+// left alone.  Tap rows no pixel of the tile has are skipped.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <string>
+
+#include "gather_gemm.h"
+
+namespace chip {
+
+// One pass over an activation / derivative tensor (CHWN fp32, C % 16 == 0, N % 64 == 0): exact three-way bf16 split into the layout
+// gpp_kernel stages from: u32x4 [channel block cb][pixel][64-image block ib][region q = plane*2 + k-group lh][image % 64], 8 bf16 =
+// channels 16*cb + 2*j + lh of one (pixel, image) — the six 1 KB regions of a (cb, pixel, ib) "slot" are contiguous, so the
+// producer moves a slot with ONE address and immediate offsets.  Thread = (cb, lh, pixel, 4 images): reads 8 channels x 4 images,
+// writes 3 x 64 B.  Values above the bf16 range saturate to +-bf16 max (split8_sat), as the filter operand does; NaN stays NaN.
+__global__ void __launch_bounds__(256) act_planes_kernel(const float* __restrict__ src, u32x4* __restrict__ out, int CB, int HW, int N4) {
+  const size_t total = (size_t)CB * 2 * HW * N4;
+  const size_t cstride = (size_t)HW * N4 * 4;   // floats per channel
+  const int IB = N4 / 16;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n4 = (int)(i % N4);
+    size_t r = i / N4;
+    const int pix = (int)(r % HW);
+    r /= HW;
+    const int lh = (int)(r & 1), cb = (int)(r >> 1);
+    const float* sp = src + ((size_t)(16 * cb + lh) * HW + pix) * (size_t)(N4 * 4) + 4 * n4;
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ld4(sp + 2 * j * cstride);
+    u32x4* o = out + ((((size_t)cb * HW + pix) * IB + (n4 >> 4)) * 6 + lh) * 64 + 4 * (n4 & 15);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = v[j][e];
+      Split8 s;
+      split8_sat(x, s);
+      o[e] = s.h;
+      o[128 + e] = s.m;
+      o[256 + e] = s.l;
+    }
+  }
+}
+
+// The filter bank for ggp_kernel's pre-split build and gpp_kernel: the exact three-way bf16 split of the re-laid bank (Split8), laid
+// out per row tile of TH rows: u32x4 [chunk][row tile rt][region q = plane*2 + lh][row % TH] — the 6*TH*16 bytes a block stages per
+// chunk are contiguous, in the order they take in LDS, so the producer wave moves them with one address and immediate offsets.
+// Rows past R (last tile) are zeros.  forward bank: rows f, chunk = tap + TYX*cb, k-slot j of k-group lh = channel 16*cb + 2*j + lh.
+__global__ void filter_planes_rt_kernel(const float* __restrict__ W, u32x4* __restrict__ out, int F, int C, int TYX, int TH) {
+  const int RT = (F + TH - 1) / TH;
+  const size_t total = (size_t)(C / 16) * TYX * 2 * RT * TH;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % (RT * TH));
+    const size_t r = i / (RT * TH);
+    const int lh = (int)(r & 1);
+    const size_t chunk = r >> 1;
+    const int tap = (int)(chunk % TYX), cb = (int)(chunk / TYX);
+    Split8 sp = {};
+    if (f < F) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = W[(size_t)f + (size_t)F * (tap + (size_t)TYX * (16 * cb + 2 * j + lh))];
+      split8_sat(x, sp);
+    }
+    u32x4* o = out + ((chunk * RT + f / TH) * 6 + lh) * TH + f % TH;
+    o[0] = sp.h;
+    o[2 * TH] = sp.m;
+    o[4 * TH] = sp.l;
+  }
+}
+// one stride class of the input-gradient bank: rows c, chunk = tap + TYXc*fb, k-slot j of k-group lh = filter 16*fb + 2*j + lh
+__global__ void dgrad_filter_planes_rt_kernel(const float* __restrict__ W, u32x4* __restrict__ out, int F, int C, int Ky, int Kx, int cy, int cx,
+                                              int sy, int sx, int TYc, int TXc, int TH) {
+  const int TYXc = TYc * TXc, RT = (C + TH - 1) / TH;
+  const size_t total = (size_t)(F / 16) * TYXc * 2 * RT * TH;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (RT * TH));
+    const size_t r = i / (RT * TH);
+    const int lh = (int)(r & 1);
+    const size_t chunk = r >> 1;
+    const int tap = (int)(chunk % TYXc), fb = (int)(chunk / TYXc);
+    const int a = tap / TXc, b = tap - a * TXc;
+    Split8 sp = {};
+    if (c < C) {
+      const float* wp = W + (size_t)F * ((cx + sx * b) + Kx * ((cy + sy * a) + (size_t)Ky * c)) + 16 * fb + lh;
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = wp[2 * j];
+      split8_sat(x, sp);
+    }
+    u32x4* o = out + ((chunk * RT + c / TH) * 6 + lh) * TH + c % TH;
+    o[0] = sp.h;
+    o[2 * TH] = sp.m;
+    o[4 * TH] = sp.l;
+  }
+}
+
+void filter_planes_rt_launch(const PatchBank& b, void* out, int TYX, int TH, const char* op) {
+  const int R = b.dgrad ? b.C : b.F, KCn = b.dgrad ? b.F : b.C;
+  const size_t work = (size_t)(KCn / 16) * TYX * 2 * divup(R, TH) * TH;
+  int nb = (int)((work + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  KernelTimer timer(b.dgrad ? "dgrad_filter_planes_kernel" : "filter_planes_kernel", op, 0.0, 10.0 * (double)R * KCn * TYX);
+  if (b.dgrad)
+    hipLaunchKernelGGL(dgrad_filter_planes_rt_kernel, dim3(nb), dim3(256), 0, stream(), b.W, static_cast<u32x4*>(out), b.F, b.C, b.Ky, b.Kx, b.cy,
+                       b.cx, b.sy, b.sx, b.TYc, b.TXc, TH);
+  else
+    hipLaunchKernelGGL(filter_planes_rt_kernel, dim3(nb), dim3(256), 0, stream(), b.W, static_cast<u32x4*>(out), b.F, b.C, TYX, TH);
+}
+
+// LDS position (16-byte units inside a 1 KB slot) of image `img` of the slot's 64: rotated inside each group of 16 by the group
+// index, so that the consumers' ds_read_b128 — lane li reads image NTC*(li % 16) + u, lanes 16..31 the next slot — touch 16
+// distinct bank quads in every 16-lane access group (natural order: 4-way conflict).  The producer applies it through its per-lane
+// source address; global memory keeps the natural image order.
+__device__ __forceinline__ int slot_pos(int img) { return (img & 48) | ((img + (img >> 4)) & 15); }
+__device__ __forceinline__ int slot_img(int pos) { return (pos & 48) | ((pos - (pos >> 4)) & 15); }
+
+// BRAW: the source slab is staged as RAW fp32 ([slot][16 k-rows][64 images], 4 KB per slot, straight from the CHWN tensor — no
+// planes pass, 4 pieces per slot instead of 6) and split by the consumers in the MFMA shadows exactly as ggp_kernel does; !BRAW: bf16
+// planes from act_planes_kernel, consumers without VALU.
+template <int WR, int WC, int MT, int CW, bool BRAW>
+__global__ __launch_bounds__(WR* WC * 64 + 64, 2) void gpp_kernel(const GGParams pin, const GGClassTable ct) {
+  constexpr int NC = WR * WC * 64;   // consumer threads
+  constexpr int NTC = CW / 32;
+  using fvec = __attribute__((ext_vector_type(NTC))) float;
+  constexpr int ROWS = WR * MT * 32;
+  constexpr int A_STAGE = 6 * ROWS * 4;   // floats: 3 planes x 2 k-groups x ROWS x 16 bytes
+  constexpr int STA = 3;                  // A ring
+  constexpr int NS = 8;                   // slots of a slab
+  constexpr int PS = BRAW ? 4 : 6;        // 1 KB pieces per slot: 16 k-rows x 64 images x 4 B, or 6 (plane, k-group) regions
+  constexpr int SLAB = PS * NS * 256;     // floats per slab
+  constexpr int NA = A_STAGE / 4 / 64;    // producer instructions per A chunk
+  constexpr int NBP = PS * NS;            // ... per slab
+  constexpr int UW = CW / 64;             // units per wave-column
+  static_assert(WC * UW == kPatchP && NTC == 4, "tile = kPatchP units of 64 images; slot_pos is the NTC = 4 swizzle");
+  static_assert(NA + NBP < 64 && NA % 2 == 0, "vmcnt immediate; batch sizes are even");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                   // [STA][A_STAGE]
+  float* Bs = smem + STA * A_STAGE;   // [2][SLAB]
+
+  const GGParams& p = pin;
+  GGTile T;
+  if (!gg_select_tile(p, ct, T)) return;
+  const int L = T.L, tsplit = T.tsplit;
+  const int row_tile = L % p.row_tiles, col_tile = L / p.row_tiles;
+  const int split = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r0 = row_tile * ROWS;
+  const int N = p.N;
+
+  // ---- the tile's units (wave-uniform) ----------------------------------------------------------------------------------
+  const int G = T.G, GX = T.GX, units = p.IB * G;
+  int u_ib[kPatchP], u_oy[kPatchP], u_ox[kPatchP], S[kPatchP];
+  bool u_ok[kPatchP];
+  int ys_f = 1 << 30, ys_l = -(1 << 30);
+#pragma unroll
+  for (int j = 0; j < kPatchP; ++j) {
+    const int U = col_tile * kPatchP + j;
+    u_ok[j] = U < units;
+    const int ib = u_ok[j] ? U / G : 0, m = u_ok[j] ? U - ib * G : 0;
+    u_ib[j] = ib;
+    u_oy[j] = m / GX;
+    u_ox[j] = m - u_oy[j] * GX;
+    if (u_ok[j]) {
+      const int ys0 = u_oy[j] * p.ssy + T.y0;
+      ys_f = min(ys_f, ys0);
+      ys_l = max(ys_l, ys0);
+    }
+    // slot base: the next pixel of the same image row shares all but one slot with its neighbour; anything else starts a fresh run
+    S[j] = j == 0 ? 0 : S[j - 1] + (!u_ok[j] ? 0 : (u_ib[j] == u_ib[j - 1] && u_oy[j] == u_oy[j - 1]) ? 1 : 3);
+  }
+
+  // ---- reduction range in SUPERCHUNKS: (16-channel block cb, tap row a, tap group g); taps of the group innermost -------------
+  const int TX = T.TX, TYX = T.TYX, TYn = TYX / TX;
+  const int ng = p.ng, gc0 = p.gcnt[0], gc1 = p.gcnt[1], gbase0 = p.gb0[0], gbase1 = p.gb0[1];
+  int a_lo = 0, a_hi = TYn - 1;
+  const bool skip = tsplit < 0 && p.splits == 1;
+  if (skip) {   // tap rows that exist for some pixel of the tile (ggp_kernel's border-tap skipping, rows only)
+    if (p.dir > 0) { a_lo = max(0, -ys_l); a_hi = min(TYn - 1, p.SH - 1 - ys_f); }
+    else { a_lo = max(0, ys_f - (p.SH - 1)); a_hi = min(TYn - 1, ys_l); }
+  }
+  const int nrow = max(0, a_hi - a_lo + 1);
+  const int nsc_all = (p.KC / BK) * nrow * ng;
+  int sc_beg = 0, sc_end = nsc_all;
+  if (!skip) {
+    const int cps = tsplit >= 0 ? p.tail_cps : p.chunks_per_split;
+    sc_beg = min(nsc_all, (tsplit >= 0 ? tsplit : split) * cps);
+    sc_end = min(nsc_all, sc_beg + cps);
+  }
+  const int nsc = sc_end - sc_beg;
+  // chunks of the range: superchunk sc belongs to group sc % ng
+  int nchunks;
+  if (ng == 1) nchunks = nsc * gc0;
+  else {
+    const int n1 = ((sc_end + 1) >> 1) - ((sc_beg + 1) >> 1);   // odd indices in [sc_beg, sc_end)
+    nchunks = (nsc - n1) * gc0 + n1 * gc1;
+  }
+
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+  if (wave == WR * WC) {
+    // ================================ producer wave ================================
+    __builtin_amdgcn_s_setprio(3);
+    if (nchunks == 0) {
+      __builtin_amdgcn_s_barrier();
+      return;
+    }
+    const char* const planes = reinterpret_cast<const char*>(p.planes);
+    const unsigned lane_off = (unsigned)slot_img(lane) * 16u;   // planes: this lane's 16 bytes of a region's 1 KB source run
+    // raw: a piece is 4 k-rows (channels) x 64 images; lane = (k-row of the piece, image quad)
+    const size_t ch_bytes = (size_t)p.SH * p.SW * N * 4;
+    const size_t lane_off_raw = (size_t)(lane >> 4) * ch_bytes + (size_t)(lane & 15) * 16;
+    const char* const rawsrc = reinterpret_cast<const char*>(p.src);
+    const int dir = p.dir, SH = p.SH, SW = p.SW, ssy = p.ssy, ssx = p.ssx;
+#ifdef CONVNET_DIAG
+    const int diag = p.prio;   // timing diagnostics (results wrong): 1 = no slab loads after the prologue, 2 = no A loads after it
+#else
+    constexpr int diag = 0;
+#endif
+    // Every LDS-DMA instruction of this wave is `global_load_lds_dwordx4 v_lane, s[base] offset:imm` with M0 rewritten once per FOUR
+    // pieces: source and destination advance by the same 1 KB per piece (the instruction's immediate offset applies to both), because
+    // act_planes_kernel / filter_planes_rt_kernel lay a slot's six regions and a chunk's twelve pieces out contiguously.  An
+    // instruction that rewrites M0 costs the issuing wave ~2.7x one that does not (tools/dma_issue, profiles/r02_kernel_experiments.md).
+    const unsigned a_lane = (unsigned)lane * 16u;
+    const char* const abase0 = reinterpret_cast<const char*>(T.A) + (size_t)row_tile * (6 * ROWS * 16);
+    const size_t a_chunk_bytes = (size_t)p.row_tiles * (6 * ROWS * 16);
+
+    // A iterator: two chunks ahead of the consumers.  (cb, a, g, i) -> filter chunk cb*TYX + a*TX + b, b = gb0[g] + i*dir*ssx
+    int A_cb, A_a, A_g, A_i, A_left = nchunks;
+    {
+      A_g = sc_beg % ng;
+      const int r = sc_beg / ng;
+      A_a = a_lo + (nrow > 0 ? r % nrow : 0);
+      A_cb = nrow > 0 ? r / nrow : 0;
+      A_i = 0;
+    }
+    auto issue_a = [&](int stage) __attribute__((always_inline)) {
+      const int b = (A_g ? gbase1 : gbase0) + A_i * dir * ssx;
+      const char* abase = abase0 + a_chunk_bytes * (size_t)(A_cb * TYX + A_a * TX + b);   // wave-uniform
+#pragma unroll
+      for (int it = 0; it < NA; it += 4) {
+        float* const ld = As + stage * A_STAGE + 256 * it;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + a_lane), (lds_ptr_t)ld, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + a_lane), (lds_ptr_t)ld, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + a_lane), (lds_ptr_t)ld, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + a_lane), (lds_ptr_t)ld, 16, 3072, 0);
+        abase += 4096;
+      }
+      --A_left;
+      if (++A_i == (A_g ? gc1 : gc0)) {
+        A_i = 0;
+        if (++A_g == ng) {
+          A_g = 0;
+          if (++A_a > a_hi) {
+            A_a = a_lo;
+            ++A_cb;
+          }
+        }
+      }
+    };
+
+    // slab iterator: one superchunk ahead.  Lane s < NS describes slot s: the source pixel of (unit j, tap slot i) with S[j] + i == s
+    int B_cb, B_a, B_g;
+    {
+      B_g = sc_beg % ng;
+      const int r = sc_beg / ng;
+      B_a = a_lo + (nrow > 0 ? r % nrow : 0);
+      B_cb = nrow > 0 ? r / nrow : 0;
+    }
+    constexpr unsigned kNoSlot = 0xFFFFFFFFu;     // no pixel of the tile reads this slot for this group: left alone
+    constexpr unsigned kZeroSlot = 0xFFFFFFFEu;   // read, but outside the image: filled with zeros
+    const int IBn = p.IB;
+    auto slot_desc = [&]() __attribute__((always_inline)) {   // -> planes: (pixel*IB + ib) of the slot's source, in slots of 6 KB; raw: float index of (pixel, image ib*64) in a channel
+      const int s = lane & (NS - 1);
+      const int cnt = B_g ? gc1 : gc0, b0 = B_g ? gbase1 : gbase0;
+      unsigned off = kNoSlot;
+#pragma unroll
+      for (int j = 0; j < kPatchP; ++j) {
+        const int i = s - S[j];
+        if (u_ok[j] && i >= 0 && i < cnt) {
+          const int ys = u_oy[j] * ssy + T.y0 + dir * B_a;
+          const int xs = u_ox[j] * ssx + T.x0 + dir * b0 + i * ssx;
+          const bool in = (unsigned)ys < (unsigned)SH && (unsigned)xs < (unsigned)SW;
+          off = !in ? kZeroSlot : BRAW ? (unsigned)((ys * SW + xs) * N + u_ib[j] * 64) : (unsigned)((ys * SW + xs) * IBn + u_ib[j]);
+        }
+      }
+      return off;
+    };
+    auto slab_next = [&]() __attribute__((always_inline)) {
+      if (++B_g == ng) {
+        B_g = 0;
+        if (++B_a > a_hi) {
+          B_a = a_lo;
+          ++B_cb;
+        }
+      }
+    };
+    // slots [S0, S1) of a slab; slot s lands at LDS offset PS*s KB (planes: regions q = plane*2 + k-group 1 KB apart, as in memory;
+    // raw: k-rows 256 B apart).  Returns the number of loads issued (PS per in-image slot).
+    const size_t cb_bytes = BRAW ? 16 * ch_bytes : (size_t)SH * SW * IBn * 6144;   // one 16-channel block of the source
+    const unsigned zero_lds = (unsigned)(size_t)(lds_ptr_t)Bs + (unsigned)lane * 16u;
+    // Issue order of a slab's slots: first the (up to four) slots tap slot 0 reads, S[j]; then S[j] + 1, then S[j] + 2.  The first
+    // four must have landed when the superchunk starts; the rest is first read by its SECOND chunk, so it may be issued as late as
+    // the last chunk of the superchunk before: every chunk of a 3-tap superchunk then carries two slots (12 pieces) of the next
+    // slab beside its 12 A pieces — the same smooth stream the A ring has — instead of 4 / 2 / 0.
+    int ord[NS];
+    {
+      unsigned seen = 0;
+      int no = 0;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) ord[q] = -1;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < kPatchP; ++j) {
+          const int sl = S[j] + i;
+          if (u_ok[j] && sl < NS && !((seen >> sl) & 1)) {
+            seen |= 1u << sl;
+#pragma unroll
+            for (int q = 0; q < NS; ++q)
+              if (q == no) ord[q] = sl;
+            ++no;
+          }
+        }
+    }
+    // positions [P0, P1) of that order
+    auto issue_slab = [&](auto P0c, auto P1c, int buf, int cb, unsigned soff) __attribute__((always_inline)) {
+      constexpr int P0 = decltype(P0c)::value, P1 = decltype(P1c)::value;
+      int n = 0;
+      static_for<P0, P1>([&](auto PP) __attribute__((always_inline)) {
+        const int sl = ord[decltype(PP)::value];
+        if (sl < 0) return;
+        const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)soff, sl);
+        if (so == kNoSlot) return;
+        float* const ld = Bs + buf * SLAB + 256 * PS * sl;
+        if (so == kZeroSlot) {
+          const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int q = 0; q < PS; ++q)
+            asm volatile("ds_write_b128 %0, %1" ::"v"(zero_lds + (unsigned)((buf * SLAB + 256 * (PS * sl + q)) * 4)), "v"(z) : "memory");
+          return;
+        }
+        if constexpr (BRAW) {
+          const char* const base = rawsrc + (size_t)cb * cb_bytes + (size_t)so * 4;   // wave-uniform: k-row 0 of the slot
+#pragma unroll
+          for (int q = 0; q < PS; ++q)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (size_t)(4 * q) * ch_bytes + lane_off_raw), (lds_ptr_t)(ld + 256 * q), 16, 0, 0);
+        } else {
+          const char* const base = planes + (size_t)cb * cb_bytes + (size_t)so * 6144;   // wave-uniform
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + lane_off), (lds_ptr_t)ld, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + lane_off), (lds_ptr_t)ld, 16, 1024, 0);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + lane_off), (lds_ptr_t)ld, 16, 2048, 0);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + lane_off), (lds_ptr_t)ld, 16, 3072, 0);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + 4096 + lane_off), (lds_ptr_t)(ld + 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + 4096 + lane_off), (lds_ptr_t)(ld + 1024), 16, 1024, 0);
+        }
+        n += PS;
+      });
+      return n;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
+    using I8 = std::integral_constant<int, NS>;
+    // wait until at most n of this wave's loads are in flight (n = what the current batch issued, always even), and for its LDS
+    // zero-fills.  vmcnt: low four bits in [3:0], high two in [15:14]; expcnt untouched; lgkmcnt(0) in [11:8].
+    auto wait_all_but = [&](int n) __attribute__((always_inline)) {
+#define GPP_VMCNT(n) (((n) & 15) | (((n) >> 4) << 14) | 0x0070)
+#define GPP_CASE(k) case k: __builtin_amdgcn_s_waitcnt(GPP_VMCNT(k)); break;
+      switch (n) {
+        GPP_CASE(0) GPP_CASE(2) GPP_CASE(4) GPP_CASE(6) GPP_CASE(8) GPP_CASE(10) GPP_CASE(12) GPP_CASE(14) GPP_CASE(16) GPP_CASE(18)
+        GPP_CASE(20) GPP_CASE(22) GPP_CASE(24) GPP_CASE(26) GPP_CASE(28) GPP_CASE(30) GPP_CASE(32) GPP_CASE(34) GPP_CASE(36) GPP_CASE(38)
+        GPP_CASE(40) GPP_CASE(42) GPP_CASE(44) GPP_CASE(46) GPP_CASE(48) GPP_CASE(50) GPP_CASE(52) GPP_CASE(54) GPP_CASE(56) GPP_CASE(58)
+        default: __builtin_amdgcn_s_waitcnt(GPP_VMCNT(60)); break;
+      }
+#undef GPP_CASE
+#undef GPP_VMCNT
+    };
+
+    // prologue: slab 0, A of chunks 0 and 1
+    {
+      const unsigned so = slot_desc();
+      issue_slab(I0{}, I8{}, 0, B_cb, so);
+      slab_next();
+    }
+    issue_a(0);
+    const bool two = A_left > 0;
+    if (two) issue_a(1);
+    wait_all_but(two ? NA : 0);
+    __builtin_amdgcn_s_barrier();
+    int fill = 2, buf = 0;
+    for (int sc = sc_beg; sc < sc_end; ++sc) {
+      const int cnt = ((sc % ng) ? gc1 : gc0);
+      const bool has_next = sc + 1 < sc_end && !(diag & 1);
+      unsigned so = 0;
+      const int ncb = B_cb;
+      if (has_next) {
+        so = slot_desc();
+        slab_next();
+      }
+      for (int t = 0; t < cnt; ++t) {
+        int n = 0;
+        if (A_left > 0 && !(diag & 2)) {
+          issue_a(fill);
+          n += NA;
+        }
+        fill = fill == STA - 1 ? 0 : fill + 1;
+        if (has_next) {
+          // the next slab goes into the buffer the previous superchunk used: tap slot 0's slots before the last chunk, the rest in it
+          if (cnt == 2) {
+            if (t == 0) n += issue_slab(I0{}, I4{}, buf ^ 1, ncb, so);
+            else n += issue_slab(I4{}, I8{}, buf ^ 1, ncb, so);
+          } else {
+            if (t == 0) n += issue_slab(I0{}, I2{}, buf ^ 1, ncb, so);
+            else if (t == 1) n += issue_slab(I2{}, I4{}, buf ^ 1, ncb, so);
+            else n += issue_slab(I4{}, I8{}, buf ^ 1, ncb, so);
+          }
+        }
+        wait_all_but(n);   // everything issued before this chunk's batch has landed: the next chunk's A and what it reads of the slabs
+        __builtin_amdgcn_s_barrier();
+      }
+      buf ^= 1;
+    }
+    return;
+  }
+
+  // ================================ consumer waves ================================
+  const int wr = wave / WC, wc = wave % WC;
+  const int li = lane & 31, lh = lane >> 5;
+  f32x16 acc[MT][NTC];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int u = 0; u < NTC; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+
+  // this lane's unit and its slot base; its NTC columns are images NTC*(li % 16) + u of that unit
+  int S_l = 0;
+  {
+    const int j = wc * UW + (NTC * li) / 64;
+#pragma unroll
+    for (int q = 0; q < kPatchP; ++q)
+      if (q == j) S_l = S[q];
+  }
+  // planes: u32x4 units inside a slab: slot base (6 regions of 64 per slot) + k-group region + swizzled image position
+  // raw: float units: slot base (16 k-rows of 64 per slot) + k-row lh + image
+  int boff[NTC];
+#pragma unroll
+  for (int u = 0; u < NTC; ++u)
+    boff[u] = BRAW ? S_l * 1024 + lh * 64 + (NTC * li) % 64 + u : S_l * 384 + lh * 64 + slot_pos((NTC * li) % 64 + u);
+  const u32x4* const Bs4 = reinterpret_cast<const u32x4*>(Bs);
+
+  __syncthreads();   // slab 0 and A chunk 0 have landed
+  if (nchunks > 0) {
+    auto load_a = [&](int st, Split8 (&fa)[MT]) __attribute__((always_inline)) {
+      const u32x4* ap = reinterpret_cast<const u32x4*>(As + st * A_STAGE) + lh * ROWS + wr * MT * 32 + li;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        fa[t].h = ap[t * 32];
+        fa[t].m = ap[2 * ROWS + t * 32];
+        fa[t].l = ap[4 * ROWS + t * 32];
+      }
+    };
+    int stage = 0, buf = 0, ti = 0, g = sc_beg % ng, cnt = g ? gc1 : gc0;
+    // the next chunk: next tap slot of this slab, or slot 0 of the other buffer
+    auto advance = [&]() __attribute__((always_inline)) {
+      if (++ti == cnt) {
+        ti = 0;
+        buf ^= 1;
+        if (++g == ng) g = 0;
+        cnt = g ? gc1 : gc0;
+      }
+      stage = stage == STA - 1 ? 0 : stage + 1;
+    };
+    Split8 fa0[MT], fa1[MT], fb[2];
+    static_assert(NTC % 2 == 0, "column parity of fb is carried across chunks");
+    if constexpr (BRAW) {
+      // ggp_kernel's consumer: a column's eight k-rows are read raw (k-slot (lh, j) = k-row 2j + lh of the slot) and split while
+      // the previous column's MFMAs run; the chunk barrier sits in front of the last column.
+      auto read_col = [&](int u, float (&x)[8]) __attribute__((always_inline)) {
+        const float* bs = Bs + buf * SLAB + ti * 1024 + boff[u];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = bs[2 * j * 64];
+      };
+      float rc[8];
+      load_a(0, fa0);
+      read_col(0, rc);
+      split8(rc, fb[0]);
+      read_col(1, rc);
+      auto chunk = [&](Split8 (&fa)[MT], Split8 (&fan)[MT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u + 1 < NTC; ++u) {
+          __builtin_amdgcn_sched_barrier(0);
+          split8(rc, fb[(u + 1) & 1]);
+          if (u + 2 < NTC) read_col(u + 2, rc);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) acc[t][u] = split_mac(fa[t], fb[u & 1], acc[t][u]);
+#pragma unroll
+          for (int i = 0; i < 6 * MT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+        __syncthreads();   // every consumer has read this chunk's A out of LDS; the producer has the next chunk (and slab) landed
+        load_a(stage, fan);
+        read_col(0, rc);
+        split8(rc, fb[NTC & 1]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t][NTC - 1] = split_mac(fa[t], fb[(NTC - 1) & 1], acc[t][NTC - 1]);
+#pragma unroll
+        for (int i = 0; i < 6 * MT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, (44 + 6 * MT - 1) / (6 * MT), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_col(1, rc);
+      };
+      int c = 0;
+      if (nchunks & 1) {
+        chunk(fa0, fa1);
+        c = 1;
+      } else {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) fa1[t] = fa0[t];
+      }
+      for (; c < nchunks; c += 2) {
+        chunk(fa1, fa0);
+        chunk(fa0, fa1);
+      }
+    } else {
+      auto load_b = [&](int u, Split8& f) __attribute__((always_inline)) {
+        const u32x4* bp = Bs4 + buf * (SLAB / 4) + ti * 384 + boff[u];
+        f.h = bp[0];
+        f.m = bp[128];
+        f.l = bp[256];
+      };
+      load_a(0, fa0);
+      load_b(0, fb[0]);
+      // one chunk = one tap of the slab: column u's 6*MT MFMAs run with column u+1's three plane reads in their shadow; the chunk
+      // barrier sits in front of the LAST column, whose MFMAs cover the next chunk's A and column-0 reads.
+      auto chunk = [&](Split8 (&fa)[MT], Split8 (&fan)[MT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u + 1 < NTC; ++u) {
+          __builtin_amdgcn_sched_barrier(0);
+          load_b(u + 1, fb[(u + 1) & 1]);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) acc[t][u] = split_mac(fa[t], fb[u & 1], acc[t][u]);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 6 * MT - 3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+        __syncthreads();   // every consumer has read this chunk's A out of LDS; the producer has the next chunk (and slab) landed
+        load_a(stage, fan);
+        load_b(0, fb[NTC & 1]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t][NTC - 1] = split_mac(fa[t], fb[(NTC - 1) & 1], acc[t][NTC - 1]);
+#pragma unroll
+        for (int i = 0; i < 3 * MT + 3; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      int c = 0;
+      if (nchunks & 1) {
+        chunk(fa0, fa1);
+        c = 1;
+      } else {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) fa1[t] = fa0[t];
+      }
+      for (; c < nchunks; c += 2) {
+        chunk(fa1, fa0);
+        chunk(fa0, fa1);
+      }
+    }
+  }
+
+  // ---- epilogue: gg_kernel's, with the unit column mapping (GGParams::patch) -------------------------------------------------
+  if (tsplit >= 0) {
+    float* pp = p.tail_partial + ((size_t)(L - p.tail_first) * p.tail_splits + tsplit) * (size_t)(ROWS * WC * CW);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        fvec v;
+#pragma unroll
+        for (int u = 0; u < NTC; ++u) v[u] = acc[t][u][reg];
+        *reinterpret_cast<fvec*>(pp + ((size_t)(t * 16 + reg) * NC + tid) * NTC) = v;
+      }
+    return;
+  }
+  gg_epilogue<WR, WC, MT, CW, true>(p, acc, row_tile, col_tile, split, T.ncols, T.GX, T.G, T.dy0, T.dx0);
+}
+
+namespace {
+
+int g_patch_mode = -1;
+inline int patch_mode() {
+  if (g_patch_mode < 0) g_patch_mode = CHIP_KNOB("CONVNET_GG_PATCH", 0);
+  return g_patch_mode;
+}
+
+template <typename Kern>
+int patch_slots(Kern kern, int threads, size_t lds) {
+  CHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int n = 0;
+  CHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), threads, lds));
+  return (n < 1 ? 1 : n) * 256;
+}
+
+}  // namespace
+
+// Can this gather (GGParams filled by conv_up_impl / conv_down_impl for ggp_kernel's tap-major pre-split path: KC > 0, apre) run on
+// gpp_kernel?  Fills the tap groups.  A tap row is cut into ssx groups of taps that are ssx apart (one group for a stride-1
+// gather): inside a group neighbouring pixels' taps coincide, slot i of pixel j+1 = slot i+1 of pixel j.
+bool patch_shape_ok(GGParams& p) {
+  if (!patch_mode() || matrix_path() == 0 || p.KC <= 0 || p.KC % BK != 0) return false;
+  if (p.N % 64 != 0 || p.GX < 4 || p.R <= 64) return false;
+  if (p.ssx < 1 || p.ssx > 2 || (p.dir < 0 && p.ssx != 1)) return false;
+  p.ng = p.ssx;
+  for (int r = 0; r < p.ng; ++r) {
+    const int cnt = p.TX > r ? (p.TX - r + p.ssx - 1) / p.ssx : 0;
+    if (cnt < 2 || cnt > 3) return false;
+    p.gcnt[r] = cnt;
+    p.gb0[r] = p.dir > 0 ? r : r + (cnt - 1) * p.ssx;
+  }
+  if (p.ng == 1) { p.gcnt[1] = p.gcnt[0]; p.gb0[1] = p.gb0[0]; }
+  return true;
+}
+
+// The split of the filter bank and of the whole source tensor (C = p.KC channels of SH x SW x N) into planes, then the gather-GEMM
+// on them.  `op` / `flops` feed the kernel timers (algorithmic work of the call).
+void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, const PatchBank& bank) {
+  constexpr int WR = 2, WC = 2, MT = 2, CW = 128;
+  constexpr int ROWS = WR * MT * 32;
+  const int C = p.KC, HW = p.SH * p.SW, N = p.N, CB = C / BK;
+  const size_t elems = (size_t)C * HW * N;
+  const int RT = divup(p.R, ROWS);
+  {
+    // filter bank -> [chunk][row tile][plane, k-group][128 rows] bf16 planes
+    const size_t welems = (size_t)CB * p.TYX * RT * ROWS * 16;
+    u32x4* ap = static_cast<u32x4*>(workspace_aux(welems * 6));
+    filter_planes_rt_launch(bank, ap, p.TYX, ROWS, op);
+    p.A = reinterpret_cast<const float*>(ap);
+    p.apre = 1;
+  }
+  // CONVNET_GG_PATCH: 1 (default) = raw fp32 slab, split by the consumers; 2 = bf16 planes of the source tensor (one more pass)
+  const bool braw = patch_mode() != 2;
+  u32x4* planes = nullptr;
+  if (!braw) {
+    planes = static_cast<u32x4*>(workspace_planes(elems * 6));
+    KernelTimer timer("act_planes_kernel", op, 0.0, 10.0 * elems);
+    const size_t work = (size_t)CB * 2 * HW * (N / 4);
+    size_t nb = (work + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(act_planes_kernel, dim3((unsigned)nb), dim3(256), 0, stream(), p.src, planes, CB, HW, N / 4);
+  }
+  p.patch = 1;
+  p.IB = N / 64;
+  p.planes = planes;
+  p.NP = N;
+  p.ncols = 0;
+  p.row_tiles = divup(p.R, ROWS);
+  p.col_tiles = divup(p.IB * p.G, kPatchP);
+  p.zero = zero_page();
+  p.prio = CHIP_DIAG_KNOB("CONVNET_GPP_DIAG", 0);
+  constexpr size_t lds_p = sizeof(float) * (3 * (6 * ROWS * 4) + 2 * (6 * 8 * 256)), lds_r = sizeof(float) * (3 * (6 * ROWS * 4) + 2 * (4 * 8 * 256));
+  static const int slots_p = patch_slots(gpp_kernel<WR, WC, MT, CW, false>, WR * WC * 64 + 64, lds_p);
+  static const int slots_r = patch_slots(gpp_kernel<WR, WC, MT, CW, true>, WR * WC * 64 + 64, lds_r);
+  const int slots = braw ? slots_r : slots_p;
+  const int tiles = p.row_tiles * p.col_tiles;
+  const int TYn = p.TYX / p.TX;
+  const int nsc = CB * TYn * p.ng;                    // superchunks of a whole reduction
+  const int kchunks = CB * p.TYX;                     // 16-deep chunks
+  const double block_rate = 230e12 / slots;
+  // split-K by wave quantisation, as gg_launch_cfg; the unit of a K-range is the superchunk
+  int splits = 1;
+  if (dst_elems > 0 && kchunks >= 16) {
+    const double fl = 2.0 * ROWS * (WC * (double)CW) * (double)p.K;
+    double best_t = 1e30;
+    for (int sp = 1; sp <= 16 && kchunks / sp >= 8 && nsc / sp >= 1; ++sp) {
+      const double rounds = std::ceil(tiles * (double)sp / slots);
+      double t = rounds * (fl / sp) / block_rate;
+      if (sp > 1) t += sizeof(float) * (double)dst_elems * (2.0 * sp + 1) / 4.0e12 + 4e-6;
+      if (t < best_t * 0.97) {
+        best_t = t;
+        splits = sp;
+      }
+    }
+  }
+  p.chunks_per_split = divup(nsc, splits);
+  splits = divup(nsc, p.chunks_per_split);
+  p.splits = splits;
+  p.slab = dst_elems;
+  p.partial = splits > 1 ? static_cast<float*>(workspace(sizeof(float) * dst_elems * splits)) : nullptr;
+  p.tail_splits = 1;
+  p.tail_partial = nullptr;
+  if (splits == 1 && dst_elems > 0 && tiles > slots && tiles % slots != 0 && kchunks >= 32) {
+    const int full = (tiles / slots) * slots, rem = tiles - full;
+    const double tile_bytes = sizeof(float) * (double)ROWS * WC * CW;
+    const double t_round = 2.0 * ROWS * (WC * (double)CW) * (double)p.K / block_rate;
+    double best = 0.95;
+    int best_s = 1;
+    for (int s = 2; s <= 8 && kchunks / s >= 8; ++s) {
+      const double cost = std::ceil(rem * (double)s / slots) / s + (rem * (s + 1.0) * tile_bytes / 4.0e12 + 6e-6) / t_round;
+      if (cost < best) {
+        best = cost;
+        best_s = s;
+      }
+    }
+    if (best_s > 1) {
+      p.tail_first = full;
+      p.tail_cps = divup(nsc, best_s);
+      p.tail_splits = divup(nsc, p.tail_cps);
+      p.tail_tf8 = full / 8;
+      p.tail_tt8 = divup(rem * p.tail_splits, 8);
+      p.tail_partial = static_cast<float*>(workspace(sizeof(float) * (size_t)rem * p.tail_splits * ROWS * WC * CW));
+    }
+  }
+  dim3 grid(p.tail_splits > 1 ? 8 * (p.tail_tf8 + p.tail_tt8) : ((tiles + 7) / 8) * 8, splits);
+  static const GGClassTable kNone = {};
+  {
+    KernelTimer timer(braw ? "gpp_kernel<2,2,2,128,raw>" : "gpp_kernel<2,2,2,128,planes>", op, flops, 0.0, 0.0);
+    if (braw) hipLaunchKernelGGL((gpp_kernel<WR, WC, MT, CW, true>), grid, dim3(WR * WC * 64 + 64), lds_r, stream(), p, kNone);
+    else hipLaunchKernelGGL((gpp_kernel<WR, WC, MT, CW, false>), grid, dim3(WR * WC * 64 + 64), lds_p, stream(), p, kNone);
+  }
+  if (p.tail_splits > 1) {
+    const int rem = tiles - p.tail_first;
+    KernelTimer timer("gg_tail_fix_kernel", op, 0.0, sizeof(float) * (double)rem * (p.tail_splits + 1) * ROWS * WC * CW);
+    hipLaunchKernelGGL((gg_tail_fix_kernel<WR, WC, MT, CW, true>), dim3(rem), dim3(WR * WC * 64), 0, stream(), p);
+  }
+  if (splits > 1) gg_reduce_launch(p, dst_elems, splits, op);
+}
+
+}  // namespace chip
+
+extern "C" {
+void convnet_hip_set_patch_mode(int mode) { chip::g_patch_mode = mode < 0 ? 0 : mode > 2 ? 2 : mode; }
+int convnet_hip_get_patch_mode(void) { return chip::patch_mode(); }
+}

@@ -35,7 +35,7 @@ struct Arena {
   void* p = nullptr;
   size_t cap = 0;
 };
-std::map<hipStream_t, Arena> g_arena[2];
+std::map<hipStream_t, Arena> g_arena[3];
 
 void* arena_get(int which, size_t bytes, size_t slack) {
   Arena& a = g_arena[which][g_stream];
@@ -53,6 +53,8 @@ void* workspace(size_t bytes) { return arena_get(0, bytes, size_t(1) << 22); }
 // Second, independent arena: the dgrad filter images live here while the same call may take
 // split-K slabs from workspace() (two simultaneous users must not share one base pointer).
 void* workspace_aux(size_t bytes) { return arena_get(1, bytes, size_t(1) << 20); }
+// Third arena: the bf16 planes of the source tensor of one gather-GEMM call (patch_gemm.hip), alive beside the other two.
+void* workspace_planes(size_t bytes) { return arena_get(2, bytes, size_t(1) << 22); }
 
 const float* zero_page() {
   static float* z = nullptr;

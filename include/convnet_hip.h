@@ -104,6 +104,14 @@ const char* convnet_hip_version(void);
  * Initial value: environment CONVNET_GG_SPLIT (0/1), else 1.  May be changed between calls at any time. */
 void convnet_hip_set_matrix_path(int path);
 int convnet_hip_get_matrix_path(void);
+/* Which gather-GEMM kernel runs conv fprop / dgrad of the 3x3 / 5x5 layers on matrix path 1 (N % 64 == 0, 16-channel blocks; same
+ * arithmetic, same results to rounding — a schedule choice, for A/B runs and tests):
+ *   0: ggp_kernel — one output pixel x 256 images per block, every tap a fresh fetch of the source;
+ *   1: gpp_kernel, raw  — 4 neighbouring pixels x 64 images per block; the source pixels of a whole tap row staged once, as fp32;
+ *   2: gpp_kernel, planes — the same tile reading the source from bf16 planes written by one extra pass (act_planes_kernel).
+ * Initial value: environment CONVNET_GG_PATCH, else 1. */
+void convnet_hip_set_patch_mode(int mode);
+int convnet_hip_get_patch_mode(void);
 const char* get_last_cuda_error(void);               /* cudamat.cuh:109 */
 int cuda_set_device(int deviceId);                   /* cudamat.cuh:116 */
 void cuda_sync_threads(void);                        /* cudamat.cuh:123 — synchronises the current stream */

@@ -1,0 +1,126 @@
+"""gpp_kernel (convnet_amd/csrc/patch_gemm.hip) — the patch-resident gather-GEMM on pre-split source planes that runs conv fprop /
+dgrad of the 3x3 and 5x5 layers on the default (bf16-split) matrix path — against the CPU oracle (the reference's conv_up /
+conv_down, cudamat_conv_gemm.cu:545-825) on geometries chosen for ITS mechanisms: tiles that wrap from one image row to the next,
+from one 64-image block to the next, the ragged last tile, tap groups of a stride-2 row, partial row tiles, border tap rows.
+Every case asserts that the patch kernel is what ran (convnet_hip_last_kernel_info), so a silent fallback cannot pass.
+Tolerance: the reference's own kernel-test metric, max|a-b| / mean|a+b| < 1e-4 (py/test_conv.py:382-392)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402
+from oracle import Geom  # noqa: E402
+from golden_cases import rel_err  # noqa: E402
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from convnet_amd.matrix import Matrix
+    from hip_adapter import HipImpl
+    Matrix.SetupCUDADevice(0)
+    Matrix.InitRandom(42)
+    from convnet_amd import _lib
+    _lib.lib.convnet_hip_set_matrix_path(1)
+    return HipImpl()
+
+
+@pytest.fixture(params=["raw", "planes"])
+def patch_mode(request, hip):
+    """Both builds of gpp_kernel (include/convnet_hip.h: convnet_hip_set_patch_mode): the source slab staged as raw fp32 and split
+    by the consumers (default), or read from bf16 planes written by act_planes_kernel."""
+    from convnet_amd import _lib
+    _lib.lib.convnet_hip_set_patch_mode(1 if request.param == "raw" else 2)
+    yield request.param
+    _lib.lib.convnet_hip_set_patch_mode(1)
+
+
+def last_kernel():
+    from convnet_amd import _lib
+    info = _lib.KernelInfo()
+    _lib.lib.convnet_hip_last_kernel_info(ctypes.byref(info))
+    return info.name.decode()
+
+
+def rnd(rng, shape):
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+# fprop needs C % 16 == 0 and F > 64; dgrad needs F % 16 == 0 and C > 64; both N % 64 == 0 and an output grid >= 4 wide
+FPROP = [
+    Geom(N=64, C=32, H=9, W=9, F=96, Ky=3, Kx=3, pady=1, padx=1),            # 9-wide rows: every third tile wraps
+    Geom(N=128, C=80, H=13, W=13, F=144, Ky=3, Kx=3, pady=1, padx=1),         # conv3/4 grid, two image blocks, partial row tile
+    Geom(N=64, C=96, H=6, W=6, F=128, Ky=3, Kx=3),                            # 4-wide output grid, no padding
+    Geom(N=64, C=80, H=15, W=15, F=96, Ky=5, Kx=5, sy=2, sx=2),               # conv2 type: tap groups {0,2,4} and {1,3} of a stride-2 row
+    Geom(N=64, C=16, H=12, W=12, F=80, Ky=4, Kx=4, sy=2, sx=2, pady=1, padx=1),  # two groups of two
+    Geom(N=64, C=48, H=7, W=10, F=72, Ky=3, Kx=3, pady=1, padx=1),            # rectangular image
+    Geom(N=64, C=32, H=8, W=8, F=100, Ky=1, Kx=3, padx=1),                    # one tap row
+    Geom(N=64, C=32, H=8, W=8, F=100, Ky=2, Kx=2),                            # group of two taps
+    Geom(N=192, C=16, H=5, W=5, F=72, Ky=3, Kx=3, pady=1, padx=1),            # 75 units: ragged last tile, three image blocks
+    Geom(N=64, C=32, H=11, W=11, F=96, Ky=3, Kx=3, pady=2, padx=2),           # padding wider than the reach of one tap
+]
+DGRAD = [
+    Geom(N=64, C=96, H=9, W=9, F=32, Ky=3, Kx=3, pady=1, padx=1),
+    Geom(N=128, C=144, H=13, W=13, F=80, Ky=3, Kx=3, pady=1, padx=1),
+    Geom(N=64, C=128, H=13, W=13, F=48, Ky=3, Kx=3),                          # conv5 type: pad 0, 11 x 11 derivatives into 13 x 13
+    Geom(N=64, C=72, H=7, W=10, F=48, Ky=3, Kx=3, pady=1, padx=1),
+    Geom(N=64, C=100, H=8, W=8, F=32, Ky=2, Kx=2),
+    Geom(N=192, C=72, H=5, W=5, F=16, Ky=3, Kx=3, pady=1, padx=1),
+]
+_id = lambda g: f"N{g.N}C{g.C}H{g.H}W{g.W}F{g.F}k{g.Ky}x{g.Kx}s{g.sy}p{g.pady}"  # noqa: E731
+
+
+@pytest.mark.parametrize("g", FPROP, ids=_id)
+def test_patch_fprop_vs_oracle(hip, patch_mode, g):
+    rng = np.random.default_rng(21)
+    x, w = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape())
+    for st in (0.0, 1.0):
+        t0 = rnd(rng, g.out_shape())
+        got = hip.conv_up(g, x, w, t0.copy(), st)
+        assert last_kernel() == "gpp_kernel(fprop)", last_kernel()
+        assert rel_err(got, oracle.port.conv_up(g, x, w, t0.copy(), st)) < TOL
+
+
+@pytest.mark.parametrize("g", DGRAD, ids=_id)
+def test_patch_dgrad_vs_oracle(hip, patch_mode, g):
+    rng = np.random.default_rng(22)
+    dy, w = rnd(rng, g.out_shape()), rnd(rng, g.filt_shape())
+    for st in (0.0, 1.0):
+        t0 = rnd(rng, g.in_shape())
+        got = hip.conv_down(g, dy, w, t0.copy(), st)
+        assert last_kernel() == "gpp_kernel(dgrad)", last_kernel()
+        assert rel_err(got, oracle.port.conv_down(g, dy, w, t0.copy(), st)) < TOL
+
+
+def test_patch_fused_bias_relu(hip, patch_mode):
+    g = Geom(N=64, C=32, H=9, W=9, F=96, Ky=3, Kx=3, pady=1, padx=1)
+    rng = np.random.default_rng(23)
+    x, w, b = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape()), rnd(rng, (g.F,))
+    fused = hip.conv_up_bias_relu(g, x, w, b, relu=True)
+    assert last_kernel() == "gpp_kernel(fprop)"
+    y = oracle.port.conv_up(g, x, w)
+    y = oracle.port.add_row_vec(y.reshape(g.F, -1), b).reshape(g.out_shape())
+    assert rel_err(fused, oracle.port.lower_bound(y, 0.0)) < TOL
+
+
+def test_patch_modes_agree_with_ggp_kernel(hip):
+    """Same exact operand splits, same six products, fp32 accumulation in a different order (taps innermost per tap row): the three
+    kernels agree to accumulation rounding, far inside the oracle tolerance."""
+    from convnet_amd import _lib
+    g = Geom(N=64, C=64, H=13, W=13, F=128, Ky=3, Kx=3, pady=1, padx=1)
+    rng = np.random.default_rng(24)
+    x, w = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape())
+    outs = []
+    for mode in (0, 1, 2):
+        _lib.lib.convnet_hip_set_patch_mode(mode)
+        outs.append(hip.conv_up(g, x, w))
+        assert last_kernel() == ("gg_kernel(fprop)" if mode == 0 else "gpp_kernel(fprop)")
+    _lib.lib.convnet_hip_set_patch_mode(1)
+    assert rel_err(outs[1], outs[0]) < 1e-5 and rel_err(outs[2], outs[0]) < 1e-5
+    assert np.array_equal(outs[1], outs[2])   # raw and planes builds: identical operands, identical order
