@@ -242,11 +242,15 @@ def ref_host_leg(args):
     cmd = [sys.executable, os.path.join(ROOT, "tools", "ref_host_bench.py"), "--model", args.model, "--batch", str(args.batch),
            "--steps", str(args.steps), "--warmup", str(args.warmup)]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        # the C++ host opts into the bf16-split products the way INTEGRATION.md §2 says (one environment variable or one call): the
+        # library's own default at the ABI is the IEEE fp32 matrix instruction
+        env = dict(os.environ, CONVNET_GG_SPLIT="1" if args.matrix_path == "split" else "0")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         j = json.loads(line)
         return {"value": round(j["value"], 2), "unit": "images/sec", "ms_per_step": round(j["ms_per_step"], 3), "steps": j["steps"],
-                "warmup": j["warmup"], "host": "reference src/*.cc unmodified -> reference Matrix (src/matrix.cc) -> this library; "
+                "warmup": j["warmup"], "matrix_path": args.matrix_path,
+                "host": "reference src/*.cc unmodified -> reference Matrix (src/matrix.cc) -> this library; "
                                                "unfused cudamat call sequence, one metric read-back per step",
                 "last_loss": j.get("last_loss")}
     except Exception as e:   # noqa: BLE001 — a reported extra, never a reason to lose the bench line
@@ -298,6 +302,8 @@ def main():
     ap.add_argument("--transport", default="torch", choices=["torch", "abi"],
                     help="gradient exchange through torch.distributed collectives (default) or through the library's own "
                          "convnet_hip_comm_* entries (the path a C/C++ host drives)")
+    ap.add_argument("--strong-selftest", action="store_true",
+                    help="run the `strong` leg (normally only with more than one rank) on one rank too; needs --force-exchange")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="STRONG scaling (SURVEY 8(d) config 4): this many images per step in total, split evenly over the ranks "
                          "(--batch is ignored); default 0 = weak scaling, --batch images on every rank")
@@ -346,7 +352,13 @@ def main():
     if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # --transport abi: the library owns the ONE RCCL communicator of the process (what a C/C++ host has); torch.distributed only
+        # carries the 128-byte id, rendezvous and the timing reductions, over gloo.  (Round 3 created torch's NCCL group here too: two
+        # RCCL communicators in one process cost 20 % of every kernel, profiles/r03_bench_dp1_abi.json.)
+        if args.transport == "abi":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         from convnet_amd.data_parallel import GradientExchange
         exchange = GradientExchange(bucket_bytes=int(args.bucket_mb * (1 << 20)), overlap=not args.no_overlap, transport=args.transport)
 
@@ -401,15 +413,29 @@ def main():
     _lib.profile_enable(False)
     prof = _lib.profile_report()
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if dist.is_initialized():
+    def max_over_ranks(x):
+        if not dist.is_initialized():
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+        return float(t.item())
+
+    def timed_steps_of(n, steps, warm):
+        for _ in range(warm):
+            n.TrainOneBatch()
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            n.TrainOneBatch()
+        sync_all()
+        return max_over_ranks(time.perf_counter() - t1)
+
+    dt = max_over_ranks(dt)
 
     # With the weight gradients / optimizer steps on a second stream, kernels of the two streams share the chip, so a launch's
     # event (and rocprofv3) duration includes what its neighbour took.  Four more steps on ONE stream, every launch timed, give the
     # dominant kernel's undisturbed rate beside the one measured in the timed region (every rank runs them: collectives inside).
-    prof_one_stream = None
+    prof_one_stream, dt_one_stream = None, None
     if not (args.no_overlap_wgrad and args.no_side_stream_update) and not args.no_kernel_timers:
         keep = (net.overlap_wgrad_, net.overlap_update_)
         net.overlap_wgrad_, net.overlap_update_ = False, False
@@ -421,6 +447,9 @@ def main():
         sync_all()
         _lib.profile_enable(False)
         prof_one_stream = _lib.profile_report()
+        # ... and the same K steps on one stream by the wall clock: `one_stream_ms_per_step` beside `ms_per_step` says what the
+        # second stream is worth on THIS box
+        dt_one_stream = timed_steps_of(net, args.steps, 1)
         net.overlap_wgrad_, net.overlap_update_ = keep
 
     other = None
@@ -442,11 +471,39 @@ def main():
                  "model_frac": round(step_flops / (dt_other / args.steps) / 1e12 /
                                      (PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS if other_name == "split" else PEAK_FP32_MATRIX_TFLOPS), 4)}
 
+    # STRONG scaling beside the weak headline, same process (a global batch of 256 split over the ranks,
+    # src/convnet.cc:429-431 semantics): the per-GPU batch 256/world with the exchange, and the same batch without it — the difference
+    # is what the exchange leaves exposed.  Only when the run itself is the weak one, on more than one rank.
     # ranks that actually took part in the gradient exchange: the process group's size, and for the C-ABI transport the library's own
     # communicator (convnet_hip_comm_size); 0 = no exchange (one GPU)
     rccl_ranks = 0
     if exchange is not None:
         rccl_ranks = _lib.lib.convnet_hip_comm_size() if args.transport == "abi" else dist.get_world_size()
+    strong_obj = None
+    if (world > 1 or (args.strong_selftest and exchange is not None)) and not strong and args.model == "alexnet" and 256 % world == 0 and not args.staged_input:
+        from convnet_amd.data_parallel import GradientExchange
+        sb = 256 // world
+        exchange.Close()
+        times = {}
+        for label in ("compute_only", "with_exchange"):
+            ex2 = GradientExchange(bucket_bytes=int(args.bucket_mb * (1 << 20)), overlap=not args.no_overlap, transport=args.transport) if label == "with_exchange" else None
+            n2 = ConvNet(text, fused=not args.unfused, process_id=rank, num_processes=world, exchange=ex2,
+                         overlap_update=not args.no_side_stream_update, overlap_wgrad=not args.no_overlap_wgrad)
+            n2.SetBatchsize(sb)
+            n2.SetupDataset(SyntheticDataHandler(n2, sb, seed=2000 + rank, num_batches=2))
+            n2.AllocateMemory(False)
+            times[label] = timed_steps_of(n2, args.steps, 3)
+            if ex2 is not None:
+                strong_ranks = _lib.lib.convnet_hip_comm_size() if args.transport == "abi" else dist.get_world_size()
+                ex2.Close()
+            del n2
+        strong_obj = {"scaling": "strong", "global_batch": 256, "batch_per_gpu": sb, "n_gpus": world, "steps": args.steps,
+                      "value": round(256 * args.steps / times["with_exchange"], 2), "unit": "images/sec",
+                      "ms_per_step": round(1e3 * times["with_exchange"] / args.steps, 3),
+                      "compute_only_ms_per_step": round(1e3 * times["compute_only"] / args.steps, 3),
+                      "exchange_exposed_ms": round(1e3 * (times["with_exchange"] - times["compute_only"]) / args.steps, 3),
+                      "rccl_ranks": strong_ranks}
+
     if rank == 0:
         images = args.batch * world * args.steps
         value = images / dt
@@ -510,7 +567,9 @@ def main():
         out = {
             "metric": "images/sec (fprop+bprop+wgrad) AlexNet 224x224 bs=256" if args.model == "alexnet" else f"images/sec {args.model}",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "host_enqueue_ms_per_step": round(1e3 * dt_enqueue / args.steps, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3),
+            "one_stream_ms_per_step": round(1e3 * dt_one_stream / args.steps, 3) if dt_one_stream else None,
+            "host_enqueue_ms_per_step": round(1e3 * dt_enqueue / args.steps, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "rccl_ranks": rccl_ranks,
             "arithmetic": ("fp32 operands, fp32 accumulation, fp32 results; GEMM products formed on the bf16 matrix pipe from exact three-way "
@@ -529,6 +588,8 @@ def main():
                        "params": net.NumParameters(), "train_gflop_per_image": round(2e-9 * train_macs, 4)},
             "roofline": roofline,
         }
+        if strong_obj is not None:
+            out["strong"] = strong_obj
         if other is not None:
             out["fp32_mfma_path" if other["matrix_path"] == "fp32" else "split_path"] = other
         if world == 1 and not args.no_cpu_baseline:

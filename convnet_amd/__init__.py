@@ -18,6 +18,15 @@ import os as _os
 # 12.1 ms per AlexNet step at the default, 11.3 ms with 8 queues (11.1 ms without the exchange) — the "0.7-0.8 ms a 1-rank exchange
 # costs" of round 2 was the second stream sharing a queue with the first.  Must be in the environment before the HIP runtime
 # initialises (the first device call), so it is set at package import; an explicit setting wins.  C/C++ hosts: INTEGRATION.md §4.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
+    import sys as _sys
+    _t = _sys.modules.get("torch")
+    if _t is not None and _t.cuda.is_initialized():
+        # too late: the HIP runtime read the variable when it initialised (import convnet_amd before the first device call, or export it)
+        import warnings as _warnings
+        _warnings.warn("convnet_amd imported after the HIP runtime initialised: GPU_MAX_HW_QUEUES stays at the runtime's default (4); "
+                       "the second stream of the training step may serialise behind the first (export GPU_MAX_HW_QUEUES=8)")
+    else:
+        _os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 __version__ = "0.1"

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libconvnet_hip.so")
-SOURCES = ["state.hip", "gather_gemm.hip", "patch_gemm.hip", "pool_norm.hip", "elementwise.hip", "input_staging.hip", "comm.hip"]
+SOURCES = ["state.hip", "gather_gemm.hip", "patch_gemm.hip", "pool_norm.hip", "elementwise.hip", "input_staging.hip", "comm.hip", "rccl_abi_check.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-inline-asm"]
 # CONVNET_BUILD_DIAG=1: compile the experiment knobs of csrc/common.h (CHIP_DIAG_KNOB) into the library.  Never set for the product.
 if os.environ.get("CONVNET_BUILD_DIAG"):

@@ -442,7 +442,7 @@ class ConvNet(TrainLoopMixin):
         if self.exchange_ is not None:
             self.exchange_.StartStep()
         if (self.overlap_update_ or self.overlap_wgrad_) and self.side_stream_ is None and torch.cuda.is_available():
-            self.side_stream_ = torch.cuda.Stream()
+            self.side_stream_ = Matrix.SharedStream("side")
         self.GetBatch(self.train_dataset_)
         self.Fprop(True)
         self.ComputeDeriv()

@@ -30,6 +30,7 @@ typedef int ncclRedOp_t;
 constexpr ncclResult_t ncclSuccess = 0;
 constexpr ncclRedOp_t ncclSum = 0;
 constexpr ncclDataType_t ncclFloat = 7;
+// rccl_abi_check.hip checks these values against <rccl/rccl.h> at build time wherever that header is installed.
 
 namespace chip {
 namespace {

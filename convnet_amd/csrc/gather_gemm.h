@@ -113,6 +113,13 @@ __device__ __forceinline__ void lds_dma4(unsigned voff, const char* s0, const ch
                ::"v"(voff), "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(lds)
                : "memory", "m0");
 }
+__device__ __forceinline__ void lds_dma2(unsigned voff, const char* s0, const char* s1, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %0, %1\n\t"
+               "global_load_lds_dwordx4 %0, %2 offset:1024"
+               ::"v"(voff), "s"(s0), "s"(s1), "s"(lds)
+               : "memory", "m0");
+}
 __device__ __forceinline__ void lds_dma1(unsigned voff, const char* s0, unsigned lds) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(s0), "s"(lds) : "memory", "m0");
 }

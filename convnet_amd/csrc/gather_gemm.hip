@@ -324,7 +324,7 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
   // Measured on conv4 (N=256): 126 TFLOP/s with the block fetch, 121 spread, 120 spread + sched_group_barrier
   // interleave — the two resident waves of a SIMD already cover each other's staging phase, so SPREAD stays off.
   constexpr bool SPREAD = false && GLDS_A && GLDS_B;
-  const int prio = p.prio;   // 0: no priority changes; 1: MFMA phase high; 2: staging phase high (see GGParams::prio)
+  const int prio = p.prio & 15;   // 0: no priority changes; 1: MFMA phase high; 2: staging phase high (see GGParams::prio)
   constexpr int NP = NA + NB, PPS = (NP + BK / 2 - 1) / (BK / 2);
   unsigned long long tr_begin = tr_begin_k, tr_loop = 0, tr_stage = 0, tr_mfma = 0, tr_sync = 0, tr_min_m = ~0ull, tr_max_m = 0, tr_min_t = ~0ull, tr_max_t = 0;
 #ifdef CONVNET_GG_TRACE
@@ -638,9 +638,18 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
     const char* const abase0 = reinterpret_cast<const char*>(T.A) + (APRE ? (size_t)row_tile * (6 * ROWS * 16) : (size_t)0);
     const size_t a_chunk_bytes = APRE ? (size_t)p.row_tiles * (6 * ROWS * 16) : (size_t)lda * (BK * 4);   // chunk index = cb*TYX + tap
 
+#ifdef CONVNET_DIAG
+    const int diag = p.prio >> 4;   // timing diagnostics (results wrong): 1 = no source staging after the prologue, 2 = no filter staging after it
+#else
+    constexpr int diag = 0;
+#endif
+    int issued = 0;
     auto issue = [&](int stage) __attribute__((always_inline)) {
       const char* abase = abase0 + a_chunk_bytes * (size_t)(cb * TYX + ta * TX + tb);   // wave-uniform
-      if constexpr (APRE) {
+      const bool skip_a = (diag & 2) && issued >= 2, skip_b = (diag & 1) && issued >= 2;
+      ++issued;
+      if (skip_a) {
+      } else if constexpr (APRE) {
         const unsigned lda0 = (unsigned)(size_t)(lds_ptr_t)(As + stage * A_STAGE);
 #pragma unroll
         for (int it = 0; it < NA; it += 4) {
@@ -657,7 +666,8 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
           __builtin_amdgcn_global_load_lds((gbl_ptr_t)ap, (lds_ptr_t)(As + stage * A_STAGE + 4 * 64 * it), 16, 0, 0);
         }
       }
-      if (ball) {
+      if (skip_b) {
+      } else if (ball) {
         // every lane reads real data: k-row `it` is one wave-uniform base (SALU) + this lane's 32-bit offset inside a channel plane,
         // and M0 is rewritten once per four k-rows — the instruction's immediate offset moves the LDS destination by 1 KB per k-row,
         // the uniform base absorbs the same 1 KB on the source side.  No VALU, a quarter of the M0 writes.
@@ -1414,7 +1424,7 @@ void gg_launch_classes(GGParams& p, GGClassTable& ct, bool vec) {
   p.NP = vec ? p.N : divup(p.N, CW) * CW;
   p.row_tiles = divup(p.R, ROWS);
   p.zero = zero_page();
-  p.prio = gg_prio_mode();
+  p.prio = gg_prio_mode() | (CHIP_DIAG_KNOB("CONVNET_GGP_DIAG", 0) << 4);
   p.splits = 1;
   p.chunks_per_split = 1 << 24;
   p.partial = nullptr;
@@ -1477,7 +1487,7 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   p.row_tiles = divup(p.R, ROWS);
   p.col_tiles = divup(p.ncols, WC);
   p.zero = zero_page();
-  p.prio = gg_prio_mode();
+  p.prio = gg_prio_mode() | (CHIP_DIAG_KNOB("CONVNET_GGP_DIAG", 0) << 4);
   const int tiles = p.row_tiles * p.col_tiles;
   const int kchunks = divup(p.K, BK);
   // 3 blocks per CU (768 slots) for launches with at least two such rounds of tiles; only the 128-row r-contiguous
@@ -2089,7 +2099,9 @@ static int dot_impl(cudamat* mat1, cudamat* mat2, cudamat* bias, cudamat* target
     t_op = t2 ? "fc_fprop" : "fc_dgrad";
     t_flops = 2.0 * m * (double)n * K;
     t_exec = 0.0;
-    p.skinny = m <= 128 && getenv("CONVNET_GG_NO_SKINNY") == nullptr;
+    // the 128-row x 64-column tile of a small per-GPU batch, for layers that fill its rows: an FC head with few outputs (R <= 64)
+    // keeps the 32- / 64-row tiles instead of padding to 128 rows
+    p.skinny = m <= 128 && n > 64 && !CHIP_DIAG_KNOB("CONVNET_GG_NO_SKINNY", 0);
     if (t2) {   // NT: A[r=f + F*k=d]
       const bool v = base_vec && n % 4 == 0;
       if (v && !p.skinny && ggp_shape_ok(n, K)) p.KC = K;   // one tap: tap-major IS channel-major, no re-layout

@@ -258,13 +258,10 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 2) void gpp_kernel(const GGParams
     auto issue_a = [&](int stage) __attribute__((always_inline)) {
       const int b = (A_g ? gbase1 : gbase0) + A_i * dir * ssx;
       const char* abase = abase0 + a_chunk_bytes * (size_t)(A_cb * TYX + A_a * TX + b);   // wave-uniform
+      const unsigned lda0 = (unsigned)(size_t)(lds_ptr_t)(As + stage * A_STAGE);
 #pragma unroll
       for (int it = 0; it < NA; it += 4) {
-        float* const ld = As + stage * A_STAGE + 256 * it;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + a_lane), (lds_ptr_t)ld, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + a_lane), (lds_ptr_t)ld, 16, 1024, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + a_lane), (lds_ptr_t)ld, 16, 2048, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(abase + a_lane), (lds_ptr_t)ld, 16, 3072, 0);
+        lds_dma4(a_lane, abase, abase, abase, abase, lda0 + 1024u * it);
         abase += 4096;
       }
       --A_left;
@@ -368,12 +365,9 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 2) void gpp_kernel(const GGParams
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (size_t)(4 * q) * ch_bytes + lane_off_raw), (lds_ptr_t)(ld + 256 * q), 16, 0, 0);
         } else {
           const char* const base = planes + (size_t)cb * cb_bytes + (size_t)so * 6144;   // wave-uniform
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + lane_off), (lds_ptr_t)ld, 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + lane_off), (lds_ptr_t)ld, 16, 1024, 0);
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + lane_off), (lds_ptr_t)ld, 16, 2048, 0);
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + lane_off), (lds_ptr_t)ld, 16, 3072, 0);
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + 4096 + lane_off), (lds_ptr_t)(ld + 1024), 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + 4096 + lane_off), (lds_ptr_t)(ld + 1024), 16, 1024, 0);
+          const unsigned l0 = (unsigned)(size_t)(lds_ptr_t)ld;
+          lds_dma4(lane_off, base, base, base, base, l0);
+          lds_dma2(lane_off, base + 4096, base + 4096, l0 + 4096u);
         }
         n += PS;
       });

@@ -557,7 +557,7 @@ inline int fixed_window(const PoolGeo& g, bool vec) {
 
 // Switches a fixed-window launch to the XCD-aware 1-D order (CONVNET_POOL_NO_XCD=1 keeps the plain 3-D grid, for A/B runs).
 inline dim3 pool_xcd_grid(PoolGeo& g, int xblocks, int rows, dim3 plain) {
-  static const bool off = [] { const char* e = getenv("CONVNET_POOL_NO_XCD"); return e && *e && *e != '0'; }();
+  const bool off = CHIP_DIAG_KNOB("CONVNET_POOL_NO_XCD", 0) != 0;
   const long long total = (long long)xblocks * rows * g.C;
   if (off || total < 64 || total > (1ll << 30)) return plain;
   g.xbx = xblocks; g.xrows = rows; g.xtotal = (int)total; g.xper = (int)((total + 7) / 8);
@@ -652,10 +652,10 @@ static void rnorm_fwd_impl(cudamat* images, cudamat* targets, int numFilters, in
   {
     const int C = numFilters;
     int LT = C <= 192 ? 64 : (C <= 384 ? 32 : (C <= 768 ? 16 : 0));
-    if (const char* f = getenv("CONVNET_RNORM_FWD_LT")) LT = atoi(f);   // tuning knob (tools/pool_bench.py)
+    if (const int f = CHIP_DIAG_KNOB("CONVNET_RNORM_FWD_LT", 0)) LT = f;   // tuning knob (tools/pool_bench.py, -DCONVNET_DIAG builds)
     if (LT) {   // LDS-tiled, read-once/write-once
       const size_t smem = sizeof(float) * (size_t)C * LT;
-      static const bool xcd = getenv("CONVNET_RNORM_NO_XCD") == nullptr;   // A/B switch for the XCD-contiguous tile order
+      const bool xcd = !CHIP_DIAG_KNOB("CONVNET_RNORM_NO_XCD", 0);   // A/B switch for the XCD-contiguous tile order
       const unsigned tiles = (unsigned)((locs + LT - 1) / LT);
       const dim3 grid(xcd ? (tiles + 7) / 8 * 8 : tiles), block(256);
 #define RN_FWD(L) hipLaunchKernelGGL(rnorm_fwd_lds_kernel<L>, grid, block, smem, stream(), images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec, relu, tiles, xcd)
@@ -692,12 +692,12 @@ void ResponseNormCrossMapUndoGemm(cudamat* outGrads, cudamat* inputs, cudamat* t
     // measured (N=256): C=96 LT 8/16/32 -> 484/291/324 us, C=256 LT 8/16/32 -> 104/83/166 us: more, smaller blocks per CU
     // (the three phases of a block do not overlap) beat longer contiguous rows
     int LT = C <= 64 ? 64 : (C <= 256 ? 16 : (C <= 512 ? 8 : 0));
-    if (const char* f = getenv("CONVNET_RNORM_UNDO_LT")) LT = atoi(f);   // tuning knob (tools/pool_bench.py)
+    if (const int f = CHIP_DIAG_KNOB("CONVNET_RNORM_UNDO_LT", 0)) LT = f;   // tuning knob (tools/pool_bench.py, -DCONVNET_DIAG builds)
     if (LT) {
       const bool vec = locs % 4 == 0 && a16(outGrads->data_device) && a16(inputs->data_device) && a16(targets->data_device);
       KernelTimer timer("rnorm_undo_kernels", "rnorm_undo", 0.0, 12.0 * total);
       const size_t smem = sizeof(float) * 3 * (size_t)C * LT;
-      static const bool xcd = getenv("CONVNET_RNORM_NO_XCD") == nullptr;   // A/B switch for the XCD-contiguous tile order
+      const bool xcd = !CHIP_DIAG_KNOB("CONVNET_RNORM_NO_XCD", 0);   // A/B switch for the XCD-contiguous tile order
       const unsigned tiles = (unsigned)((locs + LT - 1) / LT);
       const dim3 grid(xcd ? (tiles + 7) / 8 * 8 : tiles), block(256);
       CHIP_REQUIRE(smem <= 160 * 1024);

@@ -17,11 +17,11 @@ ConvnetHipKernelInfo g_info = {"none", 0.0, 0, 1};
 
 hipStream_t stream() { return g_stream; }
 
-int g_matrix_path = -1;   // -1: not decided yet (first use reads CONVNET_GG_SPLIT; default 1)
+int g_matrix_path = -1;   // -1: not decided yet (first use reads CONVNET_GG_SPLIT; default 0 = IEEE fp32 products)
 int matrix_path() {
   if (g_matrix_path < 0) {
     const char* e = getenv("CONVNET_GG_SPLIT");
-    g_matrix_path = (e && *e) ? (atoi(e) != 0 ? 1 : 0) : 1;
+    g_matrix_path = (e && *e) ? (atoi(e) != 0 ? 1 : 0) : 0;
   }
   return g_matrix_path;
 }

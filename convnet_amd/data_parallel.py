@@ -61,6 +61,12 @@ class _AbiDone:
                 raise RuntimeError("convnet_hip_comm_wait failed")
 
 
+def _destroy_library_comm():
+    from ._lib import lib
+    lib.convnet_hip_comm_sync()
+    lib.convnet_hip_comm_destroy()
+
+
 class GradientExchange:
     def __init__(self, bucket_bytes=8 << 20, overlap=True, transport="torch"):
         """``transport``: "torch" — torch.distributed collectives (backend nccl = RCCL; gloo for tests) on a torch comm stream;
@@ -92,8 +98,11 @@ class GradientExchange:
                 if rc == 0:
                     lib.convnet_hip_comm_destroy()
                 raise RuntimeError(f"convnet_hip_comm_init failed (per-rank return codes {verdicts}): " + lib.get_last_cuda_error().decode())
-            import atexit
-            atexit.register(self.Close)   # never leave a live communicator + stream to interpreter teardown
+            # never leave a live communicator + stream to interpreter teardown — without pinning this object (and through net_ its
+            # GPU buffers) for the life of the process: the finalizer holds no reference to self and also runs at exit
+            import weakref
+            self.closed_ = False
+            self._finalizer = weakref.finalize(self, _destroy_library_comm)
         self.comm_stream_ = None
         self.net_ = None
         self.bucket_of_ = {}
@@ -107,9 +116,7 @@ class GradientExchange:
     def Close(self):
         """Drains and destroys the library's communicator (transport "abi"); idempotent.  The torch process group stays the caller's."""
         if self.transport_ == "abi" and not self.closed_:
-            from ._lib import lib
-            lib.convnet_hip_comm_sync()
-            lib.convnet_hip_comm_destroy()
+            self._finalizer()   # runs _destroy_library_comm once and detaches it
         self.closed_ = True
 
     def _drain_library_comm(self):
@@ -161,7 +168,8 @@ class GradientExchange:
             if need > have:
                 raise RuntimeError(f"gradient exchange needs {need} slots per step, the library has {have}: raise bucket_bytes")
         if torch.cuda.is_available() and net.grad_parameters_.tensor().is_cuda:
-            self.comm_stream_ = torch.cuda.Stream()
+            from .matrix import Matrix
+            self.comm_stream_ = Matrix.SharedStream("comm")
 
     def StartStep(self):
         self.ready_count_ = {i: 0 for i in range(len(self.buckets_))}

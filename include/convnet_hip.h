@@ -87,21 +87,25 @@ int convnet_hip_reserve_workspace(size_t bytes);     /* optional pre-size (avoid
 const char* convnet_hip_version(void);
 /* How the GEMM-shaped kernels (conv fprop / dgrad / wgrad, dot) form their fp32 products.  Operands, accumulation and results
  * are fp32 either way.
- *   1 (default): on the bf16 matrix pipe from EXACT three-way splits x = h + m + l (each term a bf16), six of the nine cross
+ *   0 (the library's default): v_mfma_f32_32x32x2_f32 — exact fp32 products, IEEE behaviour for inf / NaN / huge operands, what a
+ *     host that links this library in place of cudamat + cublasSgemm (cudamat.cu:2130-2152) gets unless it asks otherwise.
+ *   1 (what bench.py, the Python trainer and the tests select explicitly — 1.45x the training throughput): on the bf16 matrix pipe
+ *     from EXACT three-way splits x = h + m + l (each term a bf16), six of the nine cross
  *     products per operand pair (hh, hm, mh, hl, lh, mm; the dropped ml, lm, ll are <= 2^-23 of a product), fp32 accumulate in
  *     v_mfma_f32_32x32x16_bf16.  Error against double, measured on the product kernels at the exact conv2 / conv4 / fc6 shapes
  *     (tests/test_split_arithmetic_gpu.py, profiles/r03_split_arithmetic.txt; unit 2^-24 of sum|ab|): N(0,1) data 4.2-4.7 vs
  *     4.4-6.1 for path 0 — accumulation rounding dominates both; terms 2^40 apart inside one dot product 14-19 vs 11-14; terms that
  *     cancel in pairs to 2^-12 (only exact products survive) 0.11 vs 0.05.
- *     Where path 1 is NOT plain fp32 arithmetic:
+ *     Where path 1 is NOT plain fp32 arithmetic (a split product cannot be: inf * w = inf*w_h + inf*w_m is inf - inf or inf * 0
+ *     whenever the weight's second term has the other sign or is zero):
  *       - an ACTIVATION / DERIVATIVE operand with |x| > 3.396e38 (0x7F7F7FFF; the top 0.2 % of the fp32 range, and +-inf) makes
  *         the outputs it touches NaN (its first split term is a bf16 inf, the residual inf - inf) where path 0 gives +-inf or a
  *         huge finite number.  NaN operands behave as on path 0.
- *       - a FILTER / WEIGHT operand above that range (or +-inf) saturates to +-3.3895e38 (bf16 max).
+ *       - a conv FILTER operand (pre-split outside the loops, filter_planes_rt_kernel) above that range (or +-inf) saturates to
+ *         +-3.3895e38 (bf16 max); an FC weight or a weight-gradient operand (split inside the loops) gives NaN like an activation.
  *       - operands below ~2^-110 in magnitude: their second / third split terms are denormals, which the matrix pipe flushes;
  *         the product then carries 8-16 instead of 24 significant bits (measured <= 2^-20 of sum|ab| at |x| ~ 2^-116).
- *   0: v_mfma_f32_32x32x2_f32 (round 1's path; exact fp32 products).
- * Initial value: environment CONVNET_GG_SPLIT (0/1), else 1.  May be changed between calls at any time. */
+ * Initial value: environment CONVNET_GG_SPLIT (0/1), else 0.  May be changed between calls at any time. */
 void convnet_hip_set_matrix_path(int path);
 int convnet_hip_get_matrix_path(void);
 /* Which gather-GEMM kernel runs conv fprop / dgrad of the 3x3 / 5x5 layers on matrix path 1 (N % 64 == 0, 16-channel blocks; same

@@ -35,3 +35,20 @@ def test_host_only_view_ops():
     assert _lib.lib.get_slice(ctypes.byref(m), ctypes.byref(s), 2, 5) == 0
     assert (s.size[0], s.size[1], s.owns_data) == (3, 3, 0) and s.data_device == 4096 + 2 * 3 * 4
     assert _lib.lib.get_slice(ctypes.byref(m), ctypes.byref(s), 5, 9) == -1
+
+
+def test_library_default_matrix_path_is_ieee_fp32():
+    """The C ABI's default is path 0 (v_mfma_f32_32x32x2_f32: exact fp32 products, inf / NaN as cublasSgemm gives them) — the
+    bf16-split products are something a host selects (convnet_hip_set_matrix_path(1) or CONVNET_GG_SPLIT=1), as Matrix.SetupCUDADevice
+    does for the Python trainer, the tests and bench.py.  No device call is made here."""
+    import os
+    import subprocess
+    import sys
+    code = "from convnet_amd import _lib; print(_lib.lib.convnet_hip_get_matrix_path(), _lib.lib.convnet_hip_get_patch_mode())"
+    env = {k: v for k, v in os.environ.items() if k not in ("CONVNET_GG_SPLIT", "CONVNET_GG_PATCH")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split() == ["0", "0"], out.stdout
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=dict(env, CONVNET_GG_SPLIT="1"), timeout=300)
+    assert out.stdout.split()[0] == "1", out.stdout

@@ -377,3 +377,50 @@ def test_reference_cpp_host_trains_through_the_exchange_entries(tmp_path):
         dp = host.train_dp(m, d, 3, p0, rank=0, nranks=1, comm_id=None, bucket_bytes=bucket_bytes)
         assert np.array_equal(dp, plain), bucket_bytes
     assert not np.array_equal(plain, p0)
+
+
+@pytest.mark.parametrize("N", [256, 64])
+def test_bench_configuration_two_streams_and_exchange_are_bit_identical_to_the_serial_run(nccl_one_rank, N):
+    """What bench.py times — the real AlexNet 224 x 224 at the benchmark batch, fused entry points, weight gradients AND optimizer steps
+    on the second stream — against the same net run serially on one stream, and the same again with a 1-rank gradient exchange on both
+    transports: parameters, momentum history and gradients after three steps must agree bit for bit (dropout off: the RNG stream is
+    shared state).  Stream-ordering bugs (per-stream scratch arenas, split-K slabs, tail-fix buffers, filter planes) depend on sizes
+    and timing, so this runs at the full geometry; tests/test_net_gpu.py holds the small-net version."""
+    import torch
+    from convnet_amd import models
+    from convnet_amd.convnet import ConvNet
+    from convnet_amd.datahandler import SyntheticDataHandler
+    from convnet_amd.data_parallel import GradientExchange
+    from convnet_amd import _lib
+    text = models.alexnet(dropprob=0.0)
+
+    def run(overlap, transport=None, start=None):
+        ex = GradientExchange(bucket_bytes=8 << 20, overlap=True, transport=transport) if transport else None
+        net = ConvNet(text, fused=True, exchange=ex, overlap_update=overlap, overlap_wgrad=overlap)
+        net.SetBatchsize(N)
+        net.SetupDataset(SyntheticDataHandler(net, N, seed=11, num_batches=2))
+        net.AllocateMemory(False)
+        if start is not None:
+            net.parameters_.FromNumpy(start)
+        first = net.parameters_.ToNumpy().reshape(-1).copy()
+        for _ in range(3):
+            net.TrainOneBatch()
+        torch.cuda.synchronize()
+        if transport == "abi":
+            assert _lib.lib.convnet_hip_comm_sync() == 0
+        out = {k: getattr(net, k).ToNumpy().reshape(-1).copy() for k in ("parameters_", "history_", "grad_parameters_")}
+        slices = list(net.edge_slices_.values())
+        if ex:
+            ex.Close()
+        del net
+        torch.cuda.empty_cache()
+        return first, out, slices
+
+    first, serial, slices = run(False)
+    assert not np.array_equal(first, serial["parameters_"])
+    for overlap, transport in ((True, None), (True, "torch"), (True, "abi")):
+        _, got, _ = run(overlap, transport, start=first)
+        for name in serial:
+            for off, n in slices:   # the 128-float padding between slices is never written: skip it
+                bad = np.flatnonzero(serial[name][off:off + n] != got[name][off:off + n])
+                assert bad.size == 0, (N, overlap, transport, name, off, int(bad.size), bad[:8].tolist())

@@ -373,7 +373,7 @@ def test_input_staging_is_bit_exact_vs_oracle_incl_ragged_sizes(hip):
 def test_conv_up_tail_split_more_tiles_than_slots(hip, matrix_path):
     """648 block tiles on 512 resident slots: tiles 512..647 are computed as K-split pieces whose raw sums
     gg_tail_fix_kernel adds in fixed order before the normal epilogue (accumulate / bias / ReLU).  Same result as the
-    whole-K path: CONVNET_GG_NO_TAIL_SPLIT is the A/B switch used when measuring."""
+    whole-K path (CONVNET_GG_NO_TAIL_SPLIT, a -DCONVNET_DIAG build knob, is the A/B switch used when measuring)."""
     g = Geom(N=256, C=64, H=18, W=18, F=256, Ky=3, Kx=3, pady=1, padx=1)
     rng = np.random.default_rng(41)
     x, w, b = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape()), rnd(rng, (g.F,))

@@ -29,6 +29,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+import oracle  # noqa: E402
 from oracle import Geom  # noqa: E402
 
 BF16_MAX = np.array([0x7F7F0000], np.uint32).view(np.float32)[0]         # 3.3895314e38
@@ -272,3 +273,35 @@ def test_special_values_on_both_paths(hip):
     assert set(np.unique(np.nonzero(extra)[3])) <= {20}, "only image 20 (the 3.40e38 activation) may differ in finiteness"
     ok = ~bad_s
     assert np.abs(ys[ok] - yf[ok]).max() < 1e-4 * np.abs(yf[ok]).mean()
+    # (5) an FC WEIGHT with +-inf: FC weights are split inside the loops like an activation, so the outputs they touch are
+    # non-finite on both paths (NaN on the split path where the fp32 path gives +-inf) — no saturation, a diverged run stays visible
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal((96, 64), dtype=np.float32)      # numpy (D, N) == column-major Matrix (N images, D)
+    wfc = rng.standard_normal((96, 40), dtype=np.float32)    # numpy (D, F) == Matrix (F, D)
+    wfc[17, 3], wfc[2, 9] = np.inf, -np.inf
+    t0 = np.zeros((40, 64), np.float32)                      # numpy (F, N) == Matrix (N, F)
+    ys, yf = _both_paths(lambda: hip.dot(a, wfc, t0.copy(), 0.0, 1.0, False, True))
+    bad_s, bad_f = ~np.isfinite(ys), ~np.isfinite(yf)
+    assert np.array_equal(bad_s, bad_f) and bad_f[3].all() and bad_f[9].all() and bad_f.sum() == 2 * 64
+    assert np.abs(ys[~bad_s] - yf[~bad_s]).max() < 1e-4 * np.abs(yf[~bad_f]).mean()
+
+
+def test_default_path_of_the_c_abi_gives_ieee_values_for_non_finite_operands(hip):
+    """on the library's DEFAULT matrix path (0) a +-inf / above-bf16-range activation gives the very VALUES IEEE
+    fp32 arithmetic gives (+-inf where the sum is infinite, NaN only for inf - inf), checked against numpy on the affected outputs."""
+    from convnet_amd import _lib
+    g = Geom(N=32, C=16, H=7, W=7, F=32, Ky=3, Kx=3, pady=1, padx=1)
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(g.in_shape(), dtype=np.float32)
+    w = np.abs(rng.standard_normal(g.filt_shape(), dtype=np.float32)) + np.float32(0.5)   # positive weights: no inf - inf
+    x[1, 2, 2, 3], x[4, 5, 5, 8], x[9, 0, 6, 20] = np.inf, -np.inf, np.float32(3.40e38)
+    _lib.lib.convnet_hip_set_matrix_path(0)
+    try:
+        y = hip.conv_up(g, x, w)
+    finally:
+        _lib.lib.convnet_hip_set_matrix_path(1)
+    ref = oracle.port.conv_up(g, x, w)
+    assert np.array_equal(np.isposinf(y), np.isposinf(ref)) and np.array_equal(np.isneginf(y), np.isneginf(ref))
+    assert np.isposinf(y[:, :, :, 3]).any() and np.isneginf(y[:, :, :, 8]).any() and not np.isnan(y).any()
+    fin = np.isfinite(ref)
+    assert np.abs(y[fin] - ref[fin]).max() < 1e-4 * np.abs(ref[fin & (np.abs(ref) < 1e30)]).mean() or np.allclose(y[fin], ref[fin], rtol=1e-4)

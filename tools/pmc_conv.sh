@@ -13,7 +13,7 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVES"
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
            "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum"; do
   i=$((i+1))
-  for v in 0 1; do
+  for v in 0 2; do
     CONVNET_GG_PATCH=$v timeout 120 rocprofv3 --kernel-trace --pmc $set -d "$O/p${i}_v$v" -o p --output-format csv -- python "$R/tools/layer_bench.py" --only $LAYER --reps 3 > "$O/p${i}_v$v.log" 2>&1
     echo "set $i patch=$v rc=$?"
   done
