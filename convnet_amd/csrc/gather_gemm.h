@@ -74,6 +74,12 @@ struct GGParams {
   // gpp_kernel (patch_gemm.hip): the column space is tiled by UNITS, a unit = (64-image block ib, output pixel m), unit index
   // U = ib*G + m; a block tile is kPatchP consecutive units (so normally kPatchP neighbouring pixels of one row for the same 64
   // images) and `col_tile` counts those.  The source operand is read from its bf16 planes (act_planes_kernel).
+  // ggp_kernel with a GENERIC reduction order (gk): k-rows in the filter bank's own order k = ch*TYX + a*TX + b (any channel count —
+  // conv1's C = 3), K padded to KP = a multiple of 16.  ktab[k] = byte offset of k-row k's source from the output pixel's own
+  // source position ((ch*SH + a)*SW + b)*N*4 (fprop, dir = +1); ktab[KP + k] = a << 16 | b for the border tiles' per-lane range check.
+  // Padding rows repeat row K - 1 (their filter planes are zeros).
+  const unsigned* ktab;
+  int gk;
   int patch;           // 1: gpp_kernel's column mapping in gg_epilogue / gg_tail_fix_kernel
   int IB;              // N / 64
   const void* planes;  // u32x4 [channel block cb][SH][SW][IB][region = plane*2 + k-group lh][64 images]: 8 bf16 = channels 16*cb + 2*j + lh of one (pixel, image)
@@ -373,6 +379,7 @@ struct PatchBank {   // where the filter bank of the call comes from: forward fi
 };
 // the bank as bf16 planes per row tile of TH rows (patch_gemm.hip: filter_planes_rt_kernel); out holds 96 * (KC/16) * TYX * ceil(R/TH)*TH bytes
 void filter_planes_rt_launch(const PatchBank& bank, void* out, int TYX, int TH, const char* op);
+void filter_planes_gk_launch(const float* W, void* out, int F, int K, int KP, int TH, const char* op);   // generic k order (conv1)
 bool patch_shape_ok(GGParams& p);
 void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, const PatchBank& bank);
 

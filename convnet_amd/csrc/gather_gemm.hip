@@ -25,7 +25,10 @@
 // v_mfma_f32_32x32x16_bf16 per 32x32x16 block (Split8 / split8 / split_mac below; same C/D layout, so tiles, epilogues and launch
 // logic are shared).  ggp_kernel is gg_kernel with a producer wave; its split build can read the A operand as pre-split planes.
 #include <algorithm>
+#include <array>
 #include <cmath>
+#include <map>
+#include <vector>
 #include <cstdlib>
 #include <string>
 #include <type_traits>
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
   // slowest tile.
   const int TYn = T.TYX / T.TX;
   int a_lo = 0, a_hi = TYn - 1, b_lo = 0, b_hi = T.TX - 1;
-  const bool skip = tsplit < 0 && p.splits == 1;
+  const bool skip = tsplit < 0 && p.splits == 1 && !p.gk;
   if (skip) {
     // pixel range of the tile (row-major): rows oy_f..oy_l; columns ox_f..ox_l when it stays inside one row, else the whole row
     const int m_f = (col_tile * WC * CW) / p.NP, m_l = min(T.G - 1, ((col_tile + 1) * WC * CW - 1) / p.NP);
@@ -702,6 +705,64 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
       retap();
     };
 
+    // Generic k order (GGParams::gk): chunk ci is k-rows 16*ci .. 16*ci + 15 of the bank's own order; each k-row's source is the
+    // lane's pixel position plus a per-k-row constant from a table the wave reads with scalar loads.  Tiles whose every lane has
+    // every tap inside the image (all but the border pixels) issue the chunk as four lds_dma4 groups; the others per k-row and lane.
+    int gci = kbeg / BK;
+    typedef const __attribute__((address_space(4))) unsigned* const_u32_ptr_t;   // constant address space: scalar (s_load) reads
+    const const_u32_ptr_t ktab = (const_u32_ptr_t)p.ktab;
+    const unsigned gvoff = (unsigned)((ys0 * SW + xs0) * N + bn) * 4u;
+    const bool gfast = p.gk && __builtin_amdgcn_ballot_w64(b_ok && ys0 >= 0 && ys0 + TYn <= SH && xs0 >= 0 && xs0 + TX <= SW) == ~0ull;
+    auto issue_gk = [&](int stage) __attribute__((always_inline)) {
+      if constexpr (APRE) {
+        const char* abase = abase0 + a_chunk_bytes * (size_t)gci;
+        const unsigned lda0 = (unsigned)(size_t)(lds_ptr_t)(As + stage * A_STAGE);
+#pragma unroll
+        for (int it = 0; it < NA; it += 4) {
+          if (it + 3 < NA) lds_dma4(a_lane, abase, abase, abase, abase, lda0 + 1024u * it);
+          else
+#pragma unroll
+            for (int j = it; j < NA; ++j) lds_dma1(a_lane, abase + 1024 * (j - it), lda0 + 1024u * j);
+          abase += 4096;
+        }
+      }
+      const const_u32_ptr_t tk = ktab + 16 * gci;   // wave-uniform
+      const char* const sbase = reinterpret_cast<const char*>(src);
+      const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(Bs + stage * B_STAGE);
+      if (gfast) {
+#pragma unroll
+        for (int it = 0; it < NB; it += 4)
+          lds_dma4(gvoff, sbase + (unsigned)__builtin_amdgcn_readfirstlane((int)tk[it]),
+                   sbase + (unsigned)__builtin_amdgcn_readfirstlane((int)tk[it + 1]) - 1024,
+                   sbase + (unsigned)__builtin_amdgcn_readfirstlane((int)tk[it + 2]) - 2048,
+                   sbase + (unsigned)__builtin_amdgcn_readfirstlane((int)tk[it + 3]) - 3072, lds0 + 1024u * it);
+      } else {
+        const const_u32_ptr_t tt = tk + T.K;   // packed taps
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+          const int a = (int)(tt[it] >> 16), b = (int)(tt[it] & 0xffffu);
+          const bool ok = b_ok && (unsigned)(ys0 + a) < (unsigned)SH && (unsigned)(xs0 + b) < (unsigned)SW;
+          const char* gp = ok ? sbase + ((ptrdiff_t)tk[it] + ((ptrdiff_t)(ys0 * SW + xs0) * N + bn) * 4) : reinterpret_cast<const char*>(zero);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)gp, (lds_ptr_t)(Bs + stage * B_STAGE + 4 * 64 * it), 16, 0, 0);
+        }
+      }
+      ++gci;
+    };
+    if (p.gk) {
+      if (nchunks > 0) issue_gk(0);
+      if (nchunks > 1) issue_gk(1);
+      if (nchunks > 1) __builtin_amdgcn_s_waitcnt(WAIT_ONE_CHUNK_IN_FLIGHT); else __builtin_amdgcn_s_waitcnt(WAIT_ALL_LOADS);
+      __builtin_amdgcn_s_barrier();
+      int fill = 2;
+      for (int c = 0; c < nchunks; ++c) {
+        const bool more2 = c + 2 < nchunks;
+        if (more2) issue_gk(fill);
+        fill = fill == ST - 1 ? 0 : fill + 1;
+        if (more2) __builtin_amdgcn_s_waitcnt(WAIT_ONE_CHUNK_IN_FLIGHT); else __builtin_amdgcn_s_waitcnt(WAIT_ALL_LOADS);
+        __builtin_amdgcn_s_barrier();
+      }
+      return;
+    }
     if (nchunks > 0) issue(0);
     if (nchunks > 1) issue(1);
     if (nchunks > 1) __builtin_amdgcn_s_waitcnt(WAIT_ONE_CHUNK_IN_FLIGHT); else __builtin_amdgcn_s_waitcnt(WAIT_ALL_LOADS);
@@ -1793,6 +1854,26 @@ inline bool gg_presplit_mode() {
   return gg_split_mode() && !CHIP_DIAG_KNOB("CONVNET_GG_NO_PRESPLIT", 0);
 }
 
+// k-row table of ggp_kernel's generic-k mode (GGParams::ktab), built once per geometry and kept on the device
+const unsigned* gk_table(int C, int H, int W, int N, int Ky, int Kx) {
+  static std::map<std::array<int, 6>, unsigned*> cache;
+  const std::array<int, 6> key = {C, H, W, N, Ky, Kx};
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  const int K = C * Ky * Kx, KP = divup(K, BK) * BK;
+  std::vector<unsigned> tab(2 * (size_t)KP);
+  for (int k = 0; k < KP; ++k) {
+    const int kk = std::min(k, K - 1), ch = kk / (Ky * Kx), tap = kk % (Ky * Kx), a = tap / Kx, b = tap % Kx;
+    tab[k] = (unsigned)(((size_t)(ch * H + a) * W + b) * N * 4);
+    tab[KP + k] = ((unsigned)a << 16) | (unsigned)b;
+  }
+  unsigned* d = nullptr;
+  CHIP_CHECK(hipMalloc((void**)&d, tab.size() * sizeof(unsigned)));
+  CHIP_CHECK(hipMemcpy(d, tab.data(), tab.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+  cache[key] = d;
+  return d;
+}
+
 void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* targets, Shape4D* is, Shape4D* fs, Shape4D* ts,
                   const ConvDesc& d, float scaleTargets, int relu) {
   const ConvGeo g = conv_geo(is, fs, ts, d, images, filters, targets);
@@ -1805,6 +1886,25 @@ void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* tar
   p.DW = g.Mx; p.DP = g.My * g.Mx; p.dsy = 1; p.dsx = 1; p.dy0 = 0; p.dx0 = 0;
   p.scaleTargets = scaleTargets; p.relu = relu;
   const bool vec = g.N % 4 == 0 && g.F % 4 == 0 && aligned16(p.A) && aligned16(p.src) && aligned16(p.dst);
+  if (vec && gg_presplit_mode() && gg_producer_mode() && g.C % BK != 0 && g.F > 32 && CHIP_KNOB("CONVNET_GG_GK", 1) &&
+      (size_t)g.C * g.H * g.W * g.N < (size_t(1) << 30)) {
+    // few input channels (conv1: C = 3): the producer-wave kernel in the bank's own k order, k-row sources from a table
+    const int K = g.C * g.Ky * g.Kx, KP = divup(K, BK) * BK, TH = gg_tile_rows(g.F);
+    void* planes = workspace_aux((size_t)96 * (KP / 16) * divup(g.F, TH) * TH);
+    filter_planes_gk_launch(filters->data_device, planes, g.F, K, KP, TH, "conv_fprop");
+    p.A = static_cast<const float*>(planes);
+    p.apre = 1;
+    p.gk = 1;
+    p.ktab = gk_table(g.C, g.H, g.W, g.N, g.Ky, g.Kx);
+    p.K = KP;
+    p.KC = KP;   // selects the producer-wave kernels in the launchers; the reduction itself is the table's
+    t_op = "conv_fprop";
+    t_flops = 2.0 * g.N * p.G * (double)g.F * K;
+    t_exec = 0.0;
+    gg_run<false>(p, vec, (size_t)g.N * p.DP * g.F);
+    note_kernel("gg_kernel(fprop)", t_flops, p.row_tiles * p.col_tiles, p.splits);
+    return;
+  }
   if (vec && ggp_shape_ok(g.F, g.C) && gg_presplit_mode()) {
     // patch-resident gather on pre-split source planes (patch_gemm.hip) where the geometry has one
     p.KC = g.C;

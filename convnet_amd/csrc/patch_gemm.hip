@@ -114,6 +114,38 @@ __global__ void dgrad_filter_planes_rt_kernel(const float* __restrict__ W, u32x4
   }
 }
 
+// the forward bank in its OWN k order (k = ch*TYX + tap, any channel count), K padded to KP = 16 * chunks: rows f, chunk = k / 16,
+// k-slot j of k-group lh = k-row 16*chunk + 2*j + lh; rows past F and k-rows past K are zeros.  For ggp_kernel's generic-k mode (conv1).
+__global__ void filter_planes_gk_kernel(const float* __restrict__ W, u32x4* __restrict__ out, int F, int K, int KP, int TH) {
+  const int RT = (F + TH - 1) / TH;
+  const size_t total = (size_t)(KP / 16) * 2 * RT * TH;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % (RT * TH));
+    const size_t r = i / (RT * TH);
+    const int lh = (int)(r & 1);
+    const size_t chunk = r >> 1;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * (int)chunk + 2 * j + lh;
+      x[j] = (f < F && k < K) ? W[(size_t)f + (size_t)F * k] : 0.f;
+    }
+    Split8 sp;
+    split8_sat(x, sp);
+    u32x4* o = out + ((chunk * RT + f / TH) * 6 + lh) * TH + f % TH;
+    o[0] = sp.h;
+    o[2 * TH] = sp.m;
+    o[4 * TH] = sp.l;
+  }
+}
+void filter_planes_gk_launch(const float* W, void* out, int F, int K, int KP, int TH, const char* op) {
+  const size_t work = (size_t)(KP / 16) * 2 * divup(F, TH) * TH;
+  int nb = (int)((work + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  KernelTimer timer("filter_planes_kernel", op, 0.0, 10.0 * (double)F * K);
+  hipLaunchKernelGGL(filter_planes_gk_kernel, dim3(nb), dim3(256), 0, stream(), W, static_cast<u32x4*>(out), F, K, KP, TH);
+}
+
 void filter_planes_rt_launch(const PatchBank& b, void* out, int TYX, int TH, const char* op) {
   const int R = b.dgrad ? b.C : b.F, KCn = b.dgrad ? b.F : b.C;
   const size_t work = (size_t)(KCn / 16) * TYX * 2 * divup(R, TH) * TH;
