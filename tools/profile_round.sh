@@ -3,7 +3,7 @@
 #   bench line (roofline with LIVE PMC traffic + cpu_baseline + ref_host), rocprofv3 kernel-trace stats of the same command, the two PMC
 #   traffic passes of the whole step (FETCH_SIZE and WRITE_SIZE separately — together they need 5 of the 4 TCC slots), matrix-pipe
 #   counters of conv4, per-layer table, the per-GPU batch sweep of strong scaling, the split-path arithmetic table, DP self-tests.
-# Usage: /usr/local/graft/bin/gpurun --timeout 1700 -- 'bash tools/profile_round.sh r03'
+# Usage: /usr/local/graft/bin/gpurun --timeout 1700 -- 'bash tools/profile_round.sh r04'
 TAG=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/profile_$TAG
@@ -13,6 +13,16 @@ echo "== bench (default flags: what the driver runs)"
 timeout 500 python bench.py > "$O/bench_n1.json" 2> "$O/bench_n1.err"; echo "rc=$?"; cut -c1-230 "$O/bench_n1.json"
 echo "== one-stream bench"
 timeout 200 python bench.py --no-overlap-wgrad --no-side-stream-update $Q > "$O/bench_n1_one_stream.json" 2>/dev/null; cut -c60-160 "$O/bench_n1_one_stream.json"
+echo "== same-call A/B against the previous round's library (convnet_amd/lib/libconvnet_hip_r03.so, tools/build_prev_lib.sh), where it is present"
+if [ -f convnet_amd/lib/libconvnet_hip_r03.so ]; then
+  for i in 1 2; do
+    CONVNET_HIP_LIB=libconvnet_hip_r03.so timeout 200 python bench.py $Q > "$O/bench_n1_r03lib_run$i.json" 2>/dev/null; echo "r03 lib: $(cut -c60-175 "$O/bench_n1_r03lib_run$i.json")"
+    timeout 200 python bench.py $Q > "$O/bench_n1_now_run$i.json" 2>/dev/null; echo "now    : $(cut -c60-175 "$O/bench_n1_now_run$i.json")"
+  done
+  CONVNET_HIP_LIB=libconvnet_hip_r03.so timeout 120 python tools/layer_bench.py > "$O/layer_bench_r03lib.txt" 2>&1
+fi
+echo "== gather-GEMM kernel choices of this round, same call: ggp_kernel (0, default) / gpp_kernel raw (1) / gpp_kernel planes (2)"
+for m in 0 1 2; do CONVNET_GG_PATCH=$m timeout 120 python tools/layer_bench.py --only conv > "$O/layer_bench_patch$m.txt" 2>&1; grep -h "conv4.*fprop.*g.p_kernel\|conv4.*planes" "$O/layer_bench_patch$m.txt"; done
 echo "== per-layer table"
 timeout 120 python tools/layer_bench.py > "$O/layer_bench.txt" 2>&1; grep -v amdgpu "$O/layer_bench.txt" | head -60
 timeout 120 python tools/pool_bench.py > "$O/pool_bench.txt" 2>&1
