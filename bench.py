@@ -516,7 +516,17 @@ def main():
         mfma = {k: v for k, v in fam.items() if v["flops"] > 0}
         roofline = None
         if mfma:
-            dom_name, dom = max(mfma.items(), key=lambda kv: kv[1]["ms"])
+            # The dominant kernel is the MFMA family with the most time on the chip TO ITSELF: ranked by the one-stream steps (every
+            # launch alone) where they were run.  In the timed region the weight gradients share the chip with the backward pass's other
+            # GEMMs on the second stream, so a launch's event span includes its neighbour's: ranking by those stretched spans made
+            # whichever family co-runs most look dominant.  `achieved` / `frac` below remain what the contract asks for — this family's
+            # algorithmic flops over its event spans INSIDE the timed region; `one_stream` carries its undisturbed rate.
+            rank = {}
+            for r in (prof_one_stream or []):
+                if r["flops"] > 0:
+                    rank[r["kernel"]] = rank.get(r["kernel"], 0.0) + r["ms"]
+            dom_name = max(rank, key=rank.get) if rank and max(rank, key=rank.get) in mfma else max(mfma, key=lambda k: mfma[k]["ms"])
+            dom = mfma[dom_name]
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             executed = dom["executed"] / (dom["ms"] * 1e-3) / 1e12
             all_flops = sum(v["flops"] for v in mfma.values())
@@ -540,6 +550,7 @@ def main():
                 # `achieved` counts ALGORITHMIC flops (2*N*My*Mx*F*C*Ky*Kx for every conv direction, 2*M*N*K for FC); `executed`
                 # also counts the MFMA work a dgrad gather spends on border taps that read the zero page
                 "executed": round(executed, 2), "executed_frac": round(executed / peak, 4),
+                "dominant_by": "one-stream time per step (each launch alone on the chip)" if rank else "time in the timed region",
                 "vs_fp32_instruction_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
                 **traffic_fields,
                 "flops_per_launch": dom["flops"] / dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
