@@ -230,7 +230,7 @@ def cpu_baseline(sample_n=6):   # ~13 s of CPU work on the 256-core GPU box (N=2
                       f"(eigenmat.cc:2284-2298), only its pooling/softmax loops use OpenMP"}
 
 
-def ref_host_leg(args):
+def ref_host_leg(args, dp=False):
     """The north-star driver on the same clock: the reference's UNMODIFIED C++ host (src/convnet.cc ConvNet::TrainOneBatch over its own
     Layer / Edge / SGDOptimizer / Matrix, compiled from /root/reference by oracle/Makefile into oracle/_ref/libref_host_hip.so) linked
     to this library, stepping the same model and batch.  Reported beside the product number, never part of it: it runs after the
@@ -240,7 +240,7 @@ def ref_host_leg(args):
     if not os.path.exists(so):
         return {"value": None, "note": "oracle/_ref/libref_host_hip.so not built on this box (needs /root/reference at build time)"}
     cmd = [sys.executable, os.path.join(ROOT, "tools", "ref_host_bench.py"), "--model", args.model, "--batch", str(args.batch),
-           "--steps", str(args.steps), "--warmup", str(args.warmup)]
+           "--steps", str(args.steps), "--warmup", str(args.warmup)] + (["--dp"] if dp else [])
     try:
         # the C++ host opts into the bf16-split products the way INTEGRATION.md §2 says (one environment variable or one call): the
         # library's own default at the ABI is the IEEE fp32 matrix instruction
@@ -521,11 +521,12 @@ def main():
             # GEMMs on the second stream, so a launch's event span includes its neighbour's: ranking by those stretched spans made
             # whichever family co-runs most look dominant.  `achieved` / `frac` below remain what the contract asks for — this family's
             # algorithmic flops over its event spans INSIDE the timed region; `one_stream` carries its undisturbed rate.
-            rank = {}
+            alone_ms = {}
             for r in (prof_one_stream or []):
                 if r["flops"] > 0:
-                    rank[r["kernel"]] = rank.get(r["kernel"], 0.0) + r["ms"]
-            dom_name = max(rank, key=rank.get) if rank and max(rank, key=rank.get) in mfma else max(mfma, key=lambda k: mfma[k]["ms"])
+                    alone_ms[r["kernel"]] = alone_ms.get(r["kernel"], 0.0) + r["ms"]
+            top = max(alone_ms, key=alone_ms.get) if alone_ms else None
+            dom_name = top if top in mfma else max(mfma, key=lambda k: mfma[k]["ms"])
             dom = mfma[dom_name]
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             executed = dom["executed"] / (dom["ms"] * 1e-3) / 1e12
@@ -550,7 +551,7 @@ def main():
                 # `achieved` counts ALGORITHMIC flops (2*N*My*Mx*F*C*Ky*Kx for every conv direction, 2*M*N*K for FC); `executed`
                 # also counts the MFMA work a dgrad gather spends on border taps that read the zero page
                 "executed": round(executed, 2), "executed_frac": round(executed / peak, 4),
-                "dominant_by": "one-stream time per step (each launch alone on the chip)" if rank else "time in the timed region",
+                "dominant_by": "one-stream time per step (each launch alone on the chip)" if alone_ms else "time in the timed region",
                 "vs_fp32_instruction_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
                 **traffic_fields,
                 "flops_per_launch": dom["flops"] / dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
@@ -610,6 +611,9 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
         if world == 1 and not args.no_ref_host and args.model in ("alexnet", "alexnet_nin") and not args.staged_input:
             out["ref_host"] = ref_host_leg(args)
+            # ... and the same host with the reference's data-parallel step re-expressed on the library's exchange entries
+            # (SeamDPNet), a world of one rank: what the exchange plumbing costs a C++ host
+            out["ref_host_dp"] = ref_host_leg(args, dp=True)
         result_line = json.dumps(out)
     if exchange is not None:
         exchange.Close()

@@ -609,6 +609,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
     const float* bptr;        // this lane's element of k-row 0 of the next chunk to issue
     unsigned bstride;         // bytes between consecutive k-rows for this lane (0 on the zero page)
     unsigned bvoff;           // this lane's byte offset inside ONE channel plane of the source (fast path below)
+    const bool plane_small = (size_t)SH * SW * N < (size_t(1) << 30);   // ... which must fit 32 bits
     bool ball;                // every lane of the wave has the tap: no zero-page lane in this chunk
     auto retap = [&]() __attribute__((always_inline)) {
       const int ys = ys0 + dir * ta, xs = xs0 + dir * tb;
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
       bptr = ok ? src + off : zero;
       bstride = ok ? plane_bytes : 0u;
       bvoff = poff * 4u;
-      ball = __builtin_amdgcn_ballot_w64(ok) == ~0ull;
+      ball = plane_small && __builtin_amdgcn_ballot_w64(ok) == ~0ull;
     };
     retap();
     // A stage: lane-linear [krow][ROWS]; instruction `it` covers 16-byte pieces 64*it .. 64*it+63 of the chunk.

@@ -485,6 +485,37 @@ long seam_host_train_dp(const char* model_pbtxt, const char* data_pbtxt, int ste
 }
 
 int seam_host_dp_unique_id(char* id_out) { return convnet_hip_comm_unique_id(id_out); }
+
+// seam_host_bench with the data-parallel host above as the only rank of a world of one: every bucket is posted through
+// convnet_hip_comm_allreduce_avg from Bprop and waited for in UpdateWeights (events, comm stream, slot bookkeeping all live; the
+// all-reduce itself is the identity and is skipped inside the library).  Milliseconds per step, or a negative error code.
+double seam_host_bench_dp(const char* model_pbtxt, const char* data_pbtxt, int warmup, int steps, long bucket_bytes, float* loss_out) {
+  setup_device();
+  char id[128];
+  if (convnet_hip_comm_unique_id(id) != 0) return -1.0;
+  if (convnet_hip_comm_init(0, 1, id) != 0) return -2.0;
+  double ms = 0.0;
+  {
+    SeamDPNet net(model_pbtxt, (size_t)bucket_bytes);
+    net.SetupDataset(data_pbtxt);
+    net.AllocateMemory(false);
+    net.BroadcastParameters();
+    vector<float> err;
+    for (int i = 0; i < warmup; ++i) net.OneStep(err);
+    convnet_hip_comm_sync();
+    Matrix::SyncAllDevices();
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int i = 0; i < steps; ++i) net.OneStep(err);
+    convnet_hip_comm_sync();
+    Matrix::SyncAllDevices();
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (loss_out) loss_out[0] = net.Loss();
+    ms = ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6) / (steps > 0 ? steps : 1);
+  }
+  convnet_hip_comm_destroy();
+  return ms;
+}
 #endif  // USE_CUDA
 
 // run_grad_check on a FIXED point: GradChecker::Run (src/grad_check.cc:77-140) with its random fill of the inputs and labels

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--dp", action="store_true", help="the data-parallel subclass of the reference host (oracle/seam/seam_host.cc SeamDPNet) as a 1-rank world: every gradient bucket posted through convnet_hip_comm_*")
     a = ap.parse_args()
 
     import ref_host
@@ -50,7 +51,13 @@ def main():
         out_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            ms = host.lib.seam_host_bench(m.encode(), d.encode(), a.warmup, a.steps, ctypes.byref(loss))
+            if a.dp:
+                host.lib.seam_host_bench_dp.restype = ctypes.c_double
+                host.lib.seam_host_bench_dp.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_void_p]
+                ms = host.lib.seam_host_bench_dp(m.encode(), d.encode(), a.warmup, a.steps, 8 << 20, ctypes.byref(loss))
+                assert ms > 0, f"seam_host_bench_dp failed: {ms}"
+            else:
+                ms = host.lib.seam_host_bench(m.encode(), d.encode(), a.warmup, a.steps, ctypes.byref(loss))
         finally:
             sys.stdout.flush()
             os.dup2(out_fd, 1)
