@@ -391,10 +391,10 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 2) void gpp_kernel(const GGParams
           return;
         }
         if constexpr (BRAW) {
+          // four pieces of 4 k-rows x 64 images: one M0 write, SGPR bases 4 channel planes apart (minus the 1 KB the immediate offset adds)
           const char* const base = rawsrc + (size_t)cb * cb_bytes + (size_t)so * 4;   // wave-uniform: k-row 0 of the slot
-#pragma unroll
-          for (int q = 0; q < PS; ++q)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (size_t)(4 * q) * ch_bytes + lane_off_raw), (lds_ptr_t)(ld + 256 * q), 16, 0, 0);
+          const size_t d4 = 4 * ch_bytes - 1024;
+          lds_dma4((unsigned)lane_off_raw, base, base + d4, base + 2 * d4, base + 3 * d4, (unsigned)(size_t)(lds_ptr_t)ld);
         } else {
           const char* const base = planes + (size_t)cb * cb_bytes + (size_t)so * 6144;   // wave-uniform
           const unsigned l0 = (unsigned)(size_t)(lds_ptr_t)ld;
@@ -672,6 +672,7 @@ int patch_slots(Kern kern, int threads, size_t lds) {
 bool patch_shape_ok(GGParams& p) {
   if (!patch_mode() || matrix_path() == 0 || p.KC <= 0 || p.KC % BK != 0) return false;
   if (p.N % 64 != 0 || p.GX < 4 || p.R <= 64) return false;
+  if ((size_t)p.SH * p.SW * p.N >= (size_t(1) << 28)) return false;   // the raw build's lane offset spans 3 channel planes in 32 bits
   if (p.ssx < 1 || p.ssx > 2 || (p.dir < 0 && p.ssx != 1)) return false;
   p.ng = p.ssx;
   for (int r = 0; r < p.ng; ++r) {
