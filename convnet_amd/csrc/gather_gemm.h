@@ -150,9 +150,11 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
 
 // The write-out of one block tile: accumulate into / overwrite the destination with the fused bias, ReLU and mask
 // options (fin), or store the raw sums into this split's slab.  Shared by gg_kernel and gg_tail_fix_kernel.
+// reg_lo / reg_hi: the accumulator registers (of every row tile) this call writes out — all 16 from the GEMM kernels, a quarter from
+// each of the four blocks gg_tail_fix_kernel gives a tail tile.
 template <int WR, int WC, int MT, int CW, bool VEC>
 __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT][CW / 32], int row_tile, int col_tile, int split,
-                                            int pncols, int pGX, int pG, int pdy0, int pdx0) {
+                                            int pncols, int pGX, int pG, int pdy0, int pdx0, int reg_lo = 0, int reg_hi = 16) {
   constexpr int NTC = CW / 32;
   using fvec = __attribute__((ext_vector_type(NTC))) float;
   constexpr int ROWS = WR * MT * 32;
@@ -187,7 +189,7 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT]
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = r0 + wr * MT * 32 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-      if (row >= p.R) continue;
+      if (row >= p.R || reg < reg_lo || reg >= reg_hi) continue;
       fvec v;
 #pragma unroll
       for (int u = 0; u < NTC; ++u) v[u] = acc[t][u][reg];
@@ -348,26 +350,32 @@ __device__ __forceinline__ bool gg_select_tile(const GGParams& p, const GGClassT
   return true;
 }
 
-// Sums the tail_splits partial tiles of one tail tile in fixed order and applies the normal epilogue.
+// Sums the tail_splits partial tiles of one tail tile in fixed order and applies the normal epilogue.  FOUR blocks per tile, each
+// takes accumulator registers 4q .. 4q+3 of every row tile (a quarter of the tile's rows): a launch of `rem` blocks left most of
+// the chip idle (conv2 fprop: 72 tiles, 61 us for 37 MB).
+constexpr int kTailFixParts = 4;
 template <int WR, int WC, int MT, int CW, bool VEC>
 __global__ __launch_bounds__(WR* WC * 64) void gg_tail_fix_kernel(const GGParams p) {
   constexpr int NT = WR * WC * 64, NTC = CW / 32, ROWS = WR * MT * 32;
   using fvec = __attribute__((ext_vector_type(NTC))) float;
-  const int L = p.tail_first + blockIdx.x;
+  const int tile = blockIdx.x / kTailFixParts, part = blockIdx.x % kTailFixParts;
+  const int L = p.tail_first + tile;
   const int tid = threadIdx.x;
+  const int reg_lo = part * (16 / kTailFixParts), reg_hi = reg_lo + 16 / kTailFixParts;
   f32x16 acc[MT][NTC];
-  const float* pp = p.tail_partial + (size_t)blockIdx.x * p.tail_splits * (size_t)(ROWS * WC * CW);
+  const float* pp = p.tail_partial + (size_t)tile * p.tail_splits * (size_t)(ROWS * WC * CW);
 #pragma unroll
   for (int t = 0; t < MT; ++t)
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
+      if (reg < reg_lo || reg >= reg_hi) continue;
       fvec v = *reinterpret_cast<const fvec*>(pp + ((size_t)(t * 16 + reg) * NT + tid) * NTC);
       for (int sp = 1; sp < p.tail_splits; ++sp)
         v += *reinterpret_cast<const fvec*>(pp + (size_t)sp * (ROWS * WC * CW) + ((size_t)(t * 16 + reg) * NT + tid) * NTC);
 #pragma unroll
       for (int u = 0; u < NTC; ++u) acc[t][u][reg] = v[u];
     }
-  gg_epilogue<WR, WC, MT, CW, VEC>(p, acc, L % p.row_tiles, L / p.row_tiles, 0, p.ncols, p.GX, p.G, p.dy0, p.dx0);
+  gg_epilogue<WR, WC, MT, CW, VEC>(p, acc, L % p.row_tiles, L / p.row_tiles, 0, p.ncols, p.GX, p.G, p.dy0, p.dx0, reg_lo, reg_hi);
 }
 
 // gpp_kernel (patch_gemm.hip): the patch-resident gather-GEMM on pre-split source planes.  patch_shape_ok() decides whether a gather

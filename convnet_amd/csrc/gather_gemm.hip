@@ -1587,6 +1587,20 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
         splits = sp;
       }
     }
+    // ... against the tail split below (whole-K blocks for the full rounds, only the last round's tiles cut): the same round count
+    // with a fix-up over a few tiles instead of a reduce over the whole destination (conv3 dgrad: 338 tiles on 256 slots, 3 slabs of
+    // 44 MB reduced in 35 us vs 82 tail tiles fixed in ~10)
+    if (splits > 1 && tiles > slots_launch && tiles % slots_launch != 0 && kchunks >= 32 && !CHIP_DIAG_KNOB("CONVNET_GG_NO_TAIL_SPLIT", 0)) {
+      const int full = (tiles / slots_launch) * slots_launch, rem = tiles - full;
+      const double t_round = flops / block_rate, tile_bytes = sizeof(float) * (double)ROWS * WC * CW;
+      for (int s = 2; s <= 8 && kchunks / s >= 8; ++s) {
+        const double t = (full / slots + std::ceil(rem * (double)s / slots) / s) * t_round + rem * (s + 1.0) * tile_bytes / 4.0e12 + 6e-6;
+        if (t < best_t) {
+          splits = 1;
+          break;
+        }
+      }
+    }
   }
   p.chunks_per_split = kchunks > 0 ? divup(kchunks, splits) : 1;
   splits = kchunks > 0 ? divup(kchunks, p.chunks_per_split) : 1;
@@ -1674,8 +1688,8 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   if (p.tail_splits > 1) {
     const int rem = tiles - p.tail_first;
     KernelTimer timer("gg_tail_fix_kernel", t_op, 0.0, sizeof(float) * (double)rem * (p.tail_splits + 1) * ROWS * WC * CW);
-    if (vec) hipLaunchKernelGGL((gg_tail_fix_kernel<WR, WC, MT, CW, true>), dim3(rem), block, 0, stream(), p);
-    else hipLaunchKernelGGL((gg_tail_fix_kernel<WR, WC, MT, CW, false>), dim3(rem), block, 0, stream(), p);
+    if (vec) hipLaunchKernelGGL((gg_tail_fix_kernel<WR, WC, MT, CW, true>), dim3(rem * kTailFixParts), block, 0, stream(), p);
+    else hipLaunchKernelGGL((gg_tail_fix_kernel<WR, WC, MT, CW, false>), dim3(rem * kTailFixParts), block, 0, stream(), p);
   }
   if (splits > 1) {
     KernelTimer timer("gg_reduce_kernel", t_op, 0.0, sizeof(float) * (double)dst_elems * (splits + 1));

@@ -784,7 +784,7 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
   if (p.tail_splits > 1) {
     const int rem = tiles - p.tail_first;
     KernelTimer timer("gg_tail_fix_kernel", op, 0.0, sizeof(float) * (double)rem * (p.tail_splits + 1) * ROWS * WC * CW);
-    hipLaunchKernelGGL((gg_tail_fix_kernel<WR, WC, MT, CW, true>), dim3(rem), dim3(WR * WC * 64), 0, stream(), p);
+    hipLaunchKernelGGL((gg_tail_fix_kernel<WR, WC, MT, CW, true>), dim3(rem * kTailFixParts), dim3(WR * WC * 64), 0, stream(), p);
   }
   if (splits > 1) gg_reduce_launch(p, dst_elems, splits, op);
 }
