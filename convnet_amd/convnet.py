@@ -44,12 +44,13 @@ class ConvNet(TrainLoopMixin):
         self.fused = fused
         self.overlap_update_ = bool(overlap_update)
         self.overlap_wgrad_ = bool(overlap_wgrad)
-        # Where a conv edge's weight gradient joins the second stream.  "after": behind the edge's own ComputeDown, so it runs beside
-        # what FOLLOWS the dgrad on the main stream — the previous layer's response-norm / pool undo, which are HBM-bound, instead of
-        # beside the dgrad itself, which wants the same matrix pipe (conv2: dgrad 1.1 ms alone, 2.2 ms beside its own wgrad).
-        # "before" is round 2's order.  CONVNET_WGRAD_ORDER overrides (A/B runs).
+        # Where a conv edge's weight gradient joins the second stream.  "before": as soon as the edge's output derivative is final, so it
+        # runs beside the edge's own ComputeDown; "after": behind that ComputeDown, beside what follows it on the main stream (the previous
+        # layer's response-norm / pool undo).  Same arithmetic; which pairing is faster is a property of the kernels of the day: round 3
+        # measured "after" 0.08 ms ahead; with round 4's kernels (faster gather-GEMMs, the 2 x 2-block pool undo) "before" is 0.25 ms ahead
+        # (10.98-11.00 vs 11.23-11.28 ms, same call, profiles/r04_kernel_experiments.md §4).  CONVNET_WGRAD_ORDER overrides (A/B runs).
         import os
-        self.wgrad_order_ = os.environ.get("CONVNET_WGRAD_ORDER", "after")
+        self.wgrad_order_ = os.environ.get("CONVNET_WGRAD_ORDER", "before")
         self.side_stream_ = None
         self._pending_updates = []     # [(edge, event on the main stream after its dgrad, held back?)]
         self._in_train_step = False

@@ -250,6 +250,72 @@ __global__ void __launch_bounds__(256) pool_undo_fixed_kernel(const float* __res
   *reinterpret_cast<f32x4*>(out + t) = acc;
 }
 
+// 3 x 3 stride-2 max-pool undo, one thread per 2 x 2 block of input pixels (x 4 images): the four pixels of a block are covered by
+// the SAME two pooled rows and two pooled columns (pixel tx is covered by ox with 2*ox <= tx < 2*ox + 3: the pair (tx0, tx0 + 1)
+// always meets {c, c + 1}, c = (tx0 + 1)/2 - 1), so 4 gradient + 4 activation loads serve four outputs instead of sixteen each
+// — 3 loads per output instead of 9.  Same candidate order per pixel as pool_undo_fixed_kernel (pooled row ascending, then column;
+// a window that does not cover the pixel adds 0.f), so the sums are bit-identical to it.
+__global__ void __launch_bounds__(256) pool_undo_max32_block_kernel(const float* __restrict__ images, const float* __restrict__ grads,
+                                                                    const float* __restrict__ acts, float* __restrict__ out, PoolGeo g, float st,
+                                                                    bool relu_mask) {
+  int bx, by, c;
+  if (!pool_block(g, bx, by, c)) return;
+  const int WB = (g.W + 1) >> 1;
+  const int j = bx * 256 + threadIdx.x;
+  if (j >= WB * g.nvec) return;
+  const int xb = j / g.nvec, n = 4 * (j - xb * g.nvec);
+  const int iy0 = 2 * by, ix0 = 2 * xb;
+  const int ty0 = iy0 - g.py, tx0 = ix0 - g.px;   // >= 0: py, px are the negated paddings
+  const int oy0 = (ty0 + 1) / 2 - 1, ox0 = (tx0 + 1) / 2 - 1;
+  const size_t pplane = (size_t)c * g.My * g.Mx * g.N + n;
+  f32x4 gv[2][2], av[2][2];
+  bool pok[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int oy = oy0 + a, ox = ox0 + b;
+      pok[a][b] = oy >= 0 && oy < g.My && ox >= 0 && ox < g.Mx;
+      const size_t o = pplane + (pok[a][b] ? ((size_t)oy * g.Mx + ox) * g.N : 0);
+      gv[a][b] = *reinterpret_cast<const f32x4*>(grads + o);
+      av[a][b] = *reinterpret_cast<const f32x4*>(acts + o);
+    }
+  f32x4 img[2][2];
+  bool iok[2][2];
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      iok[dy][dx] = iy0 + dy < g.H && ix0 + dx < g.W;
+      const size_t t = ((size_t)(c * g.H + (iok[dy][dx] ? iy0 + dy : iy0)) * g.W + (iok[dy][dx] ? ix0 + dx : ix0)) * g.N + n;
+      img[dy][dx] = *reinterpret_cast<const f32x4*>(images + t);
+    }
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      if (!iok[dy][dx]) continue;
+      const int ty = ty0 + dy, tx = tx0 + dx;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int oy = oy0 + a, ox = ox0 + b;
+          const bool cov = pok[a][b] && 2 * oy <= ty && ty < 2 * oy + 3 && 2 * ox <= tx && tx < 2 * ox + 3;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += (cov && img[dy][dx][e] == av[a][b][e]) ? gv[a][b][e] : 0.f;
+        }
+      float* op = out + ((size_t)(c * g.H + iy0 + dy) * g.W + ix0 + dx) * g.N + n;
+      if (st != 0.f) acc = st * *reinterpret_cast<const f32x4*>(op) + acc;
+      if (relu_mask) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = img[dy][dx][e] > 0.f ? acc[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(op) = acc;
+    }
+}
+
 // ---- cross-map response norm --------------------------------------------------------------------------
 // One lane owns 4 consecutive "locations" (a location = one (pixel, image); locations are
 // contiguous in memory) and walks the channel axis with the reference's sliding-window update
@@ -597,7 +663,13 @@ void pool_undo(cudamat* images, cudamat* grads, cudamat* acts, cudamat* targets,
   const int fx = fixed_window(g, vec);
   dim3 fgrid(divup(g.W * g.nvec, 256), g.H, g.C);
   if (fx) fgrid = pool_xcd_grid(g, fgrid.x, g.H, fgrid);
-  if (fx == 32)
+  if (fx == 32 && MAX && g.H * g.W >= 400 && CHIP_KNOB("CONVNET_POOL_UNDO_BLOCK", 1)) {   // (11 x 11 maps: 17.7 vs 16.5 us)
+    // one thread per 2 x 2 input block: a third of the loads per output
+    const int hb = (g.H + 1) / 2;
+    dim3 bgrid(divup(((g.W + 1) / 2) * g.nvec, 256), hb, g.C);
+    bgrid = pool_xcd_grid(g, bgrid.x, hb, bgrid);
+    hipLaunchKernelGGL(pool_undo_max32_block_kernel, bgrid, dim3(256), 0, stream(), im, grads->data_device, ac, targets->data_device, g, st, relu_mask);
+  } else if (fx == 32)
     hipLaunchKernelGGL((pool_undo_fixed_kernel<MAX, 3, 2>), fgrid, dim3(256), 0, stream(), im, grads->data_device, ac, targets->data_device, g,
                        st, relu_mask);
   else if (fx == 22)
