@@ -152,3 +152,44 @@ def test_register_places_a_tied_owner_where_its_last_sharer_completes():
     net.edge_slices_ = {owner2: (1280, 130), mid2: (256, 1000)}
     ex.Register(net)
     assert ex.buckets_ == [[mid2], [owner2]]
+
+
+def _worker_twice(rank, world, port, out):
+    """bench.py's order of events on more than one rank: a weak-scaling run with one exchange, then — same process, same process group —
+    the `strong` leg builds a second net and a SECOND exchange after closing the first."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = 1280 + 256
+    ok = True
+    for round_, bucket_bytes in enumerate((4 * 1100, 1 << 30)):
+        g = torch.Generator().manual_seed(1000 * round_ + 100 + rank)
+        flat = torch.randn(total, generator=g)
+        local = flat.clone()
+        net = _FakeNet(flat)
+        ex = GradientExchange(bucket_bytes=bucket_bytes, overlap=False)
+        ex.Register(net)
+        for _step in range(2):
+            ex.StartStep()
+            for e in reversed(net.e):
+                ex.GradReady(e)
+            for e in net.e:
+                ex.WaitFor(e)
+        gathered = [torch.zeros(total) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        want = sum(gathered) / world          # second step averages already-equal replicas: unchanged
+        for e, (o, n) in net.edge_slices_.items():
+            ok &= torch.allclose(flat[o:o + n], want[o:o + n], atol=1e-6)
+        ok &= ex.SumScalars([float(rank + 1), 2.0]) == [float(sum(range(1, world + 1))), 2.0 * world]
+        ex.Close()
+        ex.Close()                              # idempotent
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_two_exchanges_one_after_the_other_in_one_process_gloo():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_twice, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
