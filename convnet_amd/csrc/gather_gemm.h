@@ -86,6 +86,8 @@ struct GGParams {
   int ng, gcnt[2], gb0[2];           // tap groups of one tap row: group g = taps gb0[g] + i*dir*ssx, i < gcnt[g] (slot i of the patch)
 };
 constexpr int kPatchP = 4;   // units (pixels) per gpp_kernel block tile: 4 x 64 images = 256 columns
+constexpr int kWideP = 8;    // ... per gpw_kernel block tile: 512 columns
+constexpr int kWideNS = 12;  // slots of its slab: 8 units + 2 more taps of a 3-tap row + 2 for ONE wrap (output rows >= 8 wide)
 
 // A strided dgrad is one gather-GEMM per stride class (conv_down_impl); the classes differ only in the fields
 // below.  Passing them as a table lets ONE launch cover all classes: block b belongs to the class whose
@@ -110,6 +112,14 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 // selection of __builtin_amdgcn_global_load_lds builds a 64-bit VGPR address per piece (one or two VALU each, issued between the
 // co-resident consumer wave's MFMAs) and rewrites M0 per piece; tools/dma_issue: 27 vs 10 cycles per instruction to issue.
 // M0 is a reserved register the compiler re-materialises before each of its own uses (-Wno-inline-asm for the clobber note).
+// A wave-uniform pointer, pinned to SGPRs: the compiler is free to keep a uniform value in VGPRs (it does after a select), and the
+// "s" constraint of the staging instructions below does not move it back.
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ void lds_dma4(unsigned voff, const char* s0, const char* s1, const char* s2, const char* s3, unsigned lds) {
   asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\t"
                "global_load_lds_dwordx4 %0, %1\n\t"
@@ -117,6 +127,14 @@ __device__ __forceinline__ void lds_dma4(unsigned voff, const char* s0, const ch
                "global_load_lds_dwordx4 %0, %3 offset:2048\n\t"
                "global_load_lds_dwordx4 %0, %4 offset:3072"
                ::"v"(voff), "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(lds)
+               : "memory", "m0");
+}
+__device__ __forceinline__ void lds_dma3(unsigned voff, const char* s0, const char* s1, const char* s2, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %0, %1\n\t"
+               "global_load_lds_dwordx4 %0, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %0, %3 offset:2048"
+               ::"v"(voff), "s"(s0), "s"(s1), "s"(s2), "s"(lds)
                : "memory", "m0");
 }
 __device__ __forceinline__ void lds_dma2(unsigned voff, const char* s0, const char* s1, unsigned lds) {
@@ -167,7 +185,7 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT]
   int m, n;
   if (p.patch) {
     // unit tile: wave-column wc holds CW/64 units, lane li the images NTC*li % 64 .. + NTC - 1 of unit (NTC*li)/64 of them
-    const int U = col_tile * kPatchP + wc * (CW / 64) + (NTC * li) / 64;
+    const int U = col_tile * (WC * (CW / 64)) + wc * (CW / 64) + (NTC * li) / 64;   // WC * CW / 64 units per tile (kPatchP, kWideP)
     const int ib = U / pG;
     if (ib >= p.IB) return;
     m = U - ib * pG;

@@ -648,6 +648,385 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 2) void gpp_kernel(const GGParams
   gg_epilogue<WR, WC, MT, CW, true>(p, acc, row_tile, col_tile, split, T.ncols, T.GX, T.G, T.dy0, T.dx0);
 }
 
+// gpw_kernel: the WIDE patch tile — 128 rows x kWideP = 8 units (512 columns) per block, four waves of 128 x 128 (256 accumulator
+// registers each, so one block per CU and one wave per SIMD), NO producer wave.  3-tap rows of a stride-1 gather only (the 3 x 3 layers).
+//
+// Why this shape (profiles/r04_kernel_experiments.md §1-2): a CU moves ~1 KB of LDS-DMA per ~100 cycles however the pieces are
+// addressed, so a tile is matrix-pipe-bound only under ~15 pieces per 1 536 MFMA cycles.  ggp_kernel's 128 x 256 needs 28, gpp_kernel's
+// 24 (planes) / 20 (raw); here a chunk is 3 072 MFMA cycles per SIMD for 12 filter pieces + a third of a 12-slot raw slab (4 KB per
+// slot): 28 per 3 072 = 14.  The source stays raw fp32 — no planes pass — and each wave splits its own 128 columns (32 values per
+// lane per chunk, 1.8 VALU per MFMA; the 64 x 128 waves of ggp_kernel pay 3.7).  The filter planes are gpp_kernel's (row tiles of 128).
+// Staging is issued by the four waves themselves, with gpp_kernel's producer instructions (one M0 write and immediate-offset pieces per
+// group): per chunk every wave moves a quarter (3 KB) of the filter chunk two ahead and one slot of the next slab.  With one wave per
+// SIMD nothing hides a wave's bookkeeping, so a chunk is ONE basic block: the iterators step with selects, a slot that is outside
+// the image is a load of the zero page and a slot nobody reads a load into a dump region — every wave issues exactly 7 loads per
+// chunk and waits with a constant count in front of the chunk barrier.
+// Row tiles of 128 are exact for 384 and 256 rows; conv3/4 at 256 images are 254 tiles for 256 CUs.
+// NOT YET RUN ON HARDWARE (written at the end of round 4 with the GPU budget spent): opt-in only, patch mode 3.
+__global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const GGClassTable ct) {
+  constexpr int WC = 4, MT = 4, CW = 128, NTC = CW / 32, P = kWideP, NS = kWideNS;
+  using fvec = __attribute__((ext_vector_type(NTC))) float;
+  constexpr int NC = WC * 64;
+  constexpr int ROWS = MT * 32;
+  constexpr int A_STAGE = 6 * ROWS * 4;   // floats: 3 planes x 2 k-groups x ROWS x 16 bytes
+  constexpr int STA = 3;                  // A ring
+  constexpr int SLAB = NS * 1024;         // floats per slab: a slot is 16 k-rows x 64 images of fp32
+  static_assert(A_STAGE * 4 == WC * 3 * 1024, "three 1 KB pieces of a filter chunk per wave");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                   // [STA][A_STAGE]
+  float* Bs = smem + STA * A_STAGE;   // [2][SLAB], then a 4 KB dump slot
+
+  const GGParams& p = pin;
+  GGTile T;
+  if (!gg_select_tile(p, ct, T)) return;
+  const int L = T.L, tsplit = T.tsplit;
+  const int row_tile = L % p.row_tiles, col_tile = L / p.row_tiles;
+  const int split = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int N = p.N;
+  const int dir = p.dir, SH = p.SH, SW = p.SW;
+
+  // ---- the tile's units (wave-uniform), reduced at once to what the loop needs ---------------------------------------------------
+  //   S_l     this lane's slot base (its unit: wave wc owns units 2*wc and 2*wc + 1, lanes li < 16 the first)
+  //   my_ord  this wave's three slots of a slab, in first-needed order: the (up to eight) slots tap slot 0 reads, then what tap
+  //           slot 1 adds, then tap slot 2; position q of that order belongs to wave q % 4, step q / 4
+  //   lane s < NS describes slot s: source row / column of (unit j, tap slot i) with S[j] + i == s for tap row 0, image block
+  const int G = T.G, GX = T.GX, units = p.IB * G;
+  int ys_f = 1 << 30, ys_l = -(1 << 30);
+  int S_l = 0, my_ord[3] = {-1, -1, -1};
+  int sy_l = 0, sx_l = 0, sib_l = 0;
+  bool valid_l = false;
+  {
+    int S[P], oy[P], ox[P], ib[P];
+    bool ok[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int U = col_tile * P + j;
+      ok[j] = U < units;
+      ib[j] = ok[j] ? U / G : 0;
+      const int m = ok[j] ? U - ib[j] * G : 0;
+      oy[j] = m / GX;
+      ox[j] = m - oy[j] * GX;
+      if (ok[j]) {
+        const int ys0 = oy[j] * p.ssy + T.y0;
+        ys_f = min(ys_f, ys0);
+        ys_l = max(ys_l, ys0);
+      }
+      // the next pixel of the same image row shares all but one slot with its neighbour; anything else starts a fresh run
+      S[j] = j == 0 ? 0 : S[j - 1] + (!ok[j] ? 0 : (ib[j] == ib[j - 1] && oy[j] == oy[j - 1]) ? 1 : 3);
+    }
+    const int ju = wave * 2 + ((li >> 4) & 1), s = lane & 15;
+    unsigned seen = 0;
+    int no = 0;
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+      if (j == ju) S_l = S[j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int sl = S[j] + i;
+        if (ok[j] && sl < NS && !((seen >> sl) & 1)) {
+          seen |= 1u << sl;
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            if (no == 4 * q + wave) my_ord[q] = sl;
+          ++no;
+        }
+        if (ok[j] && sl == s) {
+          valid_l = true;
+          sy_l = oy[j] * p.ssy + T.y0;
+          sx_l = ox[j] * p.ssx + T.x0 + dir * p.gb0[0] + i * p.ssx;
+          sib_l = ib[j] * 64;
+        }
+      }
+  }
+  const bool xin_l = valid_l && (unsigned)sx_l < (unsigned)SW;
+
+  // ---- reduction range in superchunks (16-channel block cb, tap row a); three chunks (taps) each --------------------------------
+  const int TX = T.TX, TYX = T.TYX, TYn = TYX / TX;
+  int a_lo = 0, a_hi = TYn - 1;
+  const bool skip = tsplit < 0 && p.splits == 1;
+  if (skip) {   // tap rows that exist for some pixel of the tile
+    if (dir > 0) { a_lo = max(0, -ys_l); a_hi = min(TYn - 1, SH - 1 - ys_f); }
+    else { a_lo = max(0, ys_f - (SH - 1)); a_hi = min(TYn - 1, ys_l); }
+  }
+  const int nrow = max(0, a_hi - a_lo + 1);
+  const int nsc_all = (p.KC / BK) * nrow;
+  int sc_beg = 0, sc_end = nsc_all;
+  if (!skip) {
+    const int cps = tsplit >= 0 ? p.tail_cps : p.chunks_per_split;
+    sc_beg = min(nsc_all, (tsplit >= 0 ? tsplit : split) * cps);
+    sc_end = min(nsc_all, sc_beg + cps);
+  }
+  const int nchunks = 3 * (sc_end - sc_beg);
+
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  f32x16 acc[MT][NTC];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int u = 0; u < NTC; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+
+  if (nchunks > 0) {
+    // ================================ staging (every wave its share) ================================
+    const size_t ch_bytes = (size_t)SH * SW * N * 4;
+    // a slot piece is 4 k-rows (channels) x 64 images: lane = (k-row of the piece, image quad)
+    const unsigned lane_off_raw = (unsigned)((size_t)(lane >> 4) * ch_bytes + (size_t)(lane & 15) * 16);
+    const char* const rawsrc = reinterpret_cast<const char*>(p.src);
+    const char* const zero_page = reinterpret_cast<const char*>(p.zero);
+    const unsigned a_lane = (unsigned)lane * 16u;
+    const char* const abase0 = reinterpret_cast<const char*>(T.A) + (size_t)row_tile * (6 * ROWS * 16) + 3072u * wave;
+    const size_t a_chunk_bytes = (size_t)p.row_tiles * (6 * ROWS * 16);
+    const unsigned lds_a = (unsigned)(size_t)(lds_ptr_t)As + 3072u * wave;
+    const unsigned lds_b = (unsigned)(size_t)(lds_ptr_t)Bs;
+    const unsigned lds_dump = lds_b + 2u * SLAB * 4u;
+    const int gb = p.gb0[0], dstep = dir * p.ssx;   // tap of tap slot i: gb + i*dstep
+
+    // Everything below steps with selects between values that are already computed — no lazily evaluated side, nothing the compiler
+    // turns into a branch (check the ISA after an edit: `s_cbranch` between two `s_barrier`s of the loop means a chunk is no longer one block).
+    // filter iterator, two chunks ahead of the MFMAs: tap slot i of tap row a of channel block cb is filter chunk cb*TYX + a*TX + gb
+    // + i*dstep; a running pointer and the three byte steps (next tap / next tap row / next channel block).  Past the end it stays on
+    // the last chunk (those loads go to a stage nobody reads any more).
+    // (as differences: a select between two captured variables becomes a load through a selected ADDRESS and sends the whole closure to scratch)
+    const ptrdiff_t a_tap = (ptrdiff_t)a_chunk_bytes * dstep, a_row_x = (ptrdiff_t)a_chunk_bytes * (TX - 3 * dstep),
+                    a_cbs_x = (ptrdiff_t)a_chunk_bytes * (TYX - (a_hi - a_lo + 1) * TX);
+    const char* a_ptr = abase0 + a_chunk_bytes * (size_t)((sc_beg / nrow) * TYX + (a_lo + sc_beg % nrow) * TX + gb);   // wave-uniform
+    // counters as plain integer arithmetic (0/1 flags, masks): booleans with && / ?: come back from the optimizer as branches
+    int A_i = 0, A_r = sc_beg % nrow, A_left = nchunks;   // tap slot, tap row - a_lo, chunks not yet issued
+    unsigned lds_f0 = lds_a, lds_f1 = lds_a + A_STAGE * 4u, lds_f2 = lds_a + 2u * A_STAGE * 4u;   // the ring stage to fill next first
+    auto issue_a = [&]() __attribute__((always_inline)) {
+      const char* const ap = uniform_ptr(a_ptr);
+      lds_dma3(a_lane, ap, ap, ap, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_f0));
+      const unsigned f = lds_f0;
+      lds_f0 = lds_f1;
+      lds_f1 = lds_f2;
+      lds_f2 = f;
+      --A_left;
+      const int more = (int)((unsigned)(-A_left) >> 31);   // 1 while chunks are left
+      const int i1 = A_i + 1, w1 = (i1 * 11) >> 5;          // w1 = 1 when the tap row is complete (i1 == 3)
+      A_i = i1 - 3 * w1;
+      const int r1 = A_r + w1, w2 = 1 - (int)((unsigned)(r1 - nrow) >> 31);   // w2 = 1 when the channel block is complete (r1 == nrow)
+      A_r = r1 - nrow * w2;
+      const ptrdiff_t d = a_tap + (-(ptrdiff_t)w1 & a_row_x) + (-(ptrdiff_t)w2 & a_cbs_x);   // next tap / + next row / + next block
+      a_ptr += -(ptrdiff_t)more & d;
+    };
+    // slab iterator, one superchunk ahead: tap row and the source pointer of its channel block
+    int B_r = A_r;   // tap row - a_lo
+    const size_t cb_bytes = 16 * ch_bytes;   // one 16-channel block of the source
+    const char* slab_src = rawsrc + (size_t)(sc_beg / nrow) * cb_bytes;
+    auto slab_next = [&](int step) __attribute__((always_inline)) {   // step: 0 / 1
+      const int r1 = B_r + step, w = 1 - (int)((unsigned)(r1 - nrow) >> 31);
+      B_r = r1 - nrow * w;
+      slab_src += -(ptrdiff_t)w & (ptrdiff_t)cb_bytes;
+    };
+    constexpr unsigned kNoSlot = 0xFFFFFFFFu;     // no unit of the tile reads this slot: the load goes to the dump region
+    constexpr unsigned kZeroSlot = 0xFFFFFFFEu;   // read, but outside the image: loaded from the zero page
+    auto slot_desc = [&](int a) __attribute__((always_inline)) {   // -> float index of (pixel, image ib*64) inside a channel plane
+      const int ys = sy_l + dir * a;
+      const unsigned off = (unsigned)((ys * SW + sx_l) * N + sib_l);
+      const bool in = xin_l && (unsigned)ys < (unsigned)SH;
+      const unsigned o1 = in ? off : kZeroSlot;
+      return valid_l ? o1 : kNoSlot;
+    };
+    const ptrdiff_t d4 = (ptrdiff_t)(4 * ch_bytes) - 1024;   // four channel planes on, minus the 1 KB the immediate offset adds
+    // slot sl (< 0: none) of the slab described by soff from source block `src` into the slab buffer at LDS address ldbuf
+    auto issue_slot = [&](int sl, unsigned ldbuf, const char* src, unsigned soff, bool enable) __attribute__((always_inline)) {
+      const int slc = sl < 0 ? 0 : sl;
+      const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)soff, slc);
+      // (the two flags through readfirstlane: as plain booleans the compiler keeps them as lane masks and moves the address selects,
+      // all wave-uniform, to the vector ALU — the staging instruction wants them in SGPRs)
+      const bool none = __builtin_amdgcn_readfirstlane((int)(!enable || sl < 0 || so == kNoSlot)) != 0;
+      const bool real = __builtin_amdgcn_readfirstlane((int)(!none && so != kZeroSlot)) != 0;
+      const char* const rbase = src + (size_t)so * 4;   // wave-uniform: k-row 0 of the slot
+      const char* const base = real ? rbase : zero_page;
+      const ptrdiff_t st = real ? d4 : (ptrdiff_t)-1024;
+      const unsigned voff = real ? lane_off_raw : 0u;
+      const unsigned ldr = ldbuf + (unsigned)slc * 4096u;
+      const unsigned ld = none ? lds_dump : ldr;
+      lds_dma4(voff, uniform_ptr(base), uniform_ptr(base + st), uniform_ptr(base + 2 * st), uniform_ptr(base + 3 * st),
+               (unsigned)__builtin_amdgcn_readfirstlane((int)ld));
+    };
+
+    // ================================ consumer state ================================
+    const int boff = S_l * 1024 + lh * 64 + NTC * (li & 15);   // floats inside a slab: slot base + k-row lh + first image
+    auto load_a = [&](int st, Split8 (&fa)[MT]) __attribute__((always_inline)) {
+      const u32x4* ap = reinterpret_cast<const u32x4*>(As + st * A_STAGE) + lh * ROWS + li;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        fa[t].h = ap[t * 32];
+        fa[t].m = ap[2 * ROWS + t * 32];
+        fa[t].l = ap[4 * ROWS + t * 32];
+      }
+    };
+    int stage = 0, ti = 0, sc = sc_beg;
+    unsigned bufsel = 0;   // 0 / 1: the slab buffer the MFMAs read
+    // k-slot (lh, j) of a column = k-row 2j + lh of the slot; one 16-byte read per k-row brings this lane's NTC images
+    f32x4 bv[8];
+    auto read_b = [&]() __attribute__((always_inline)) {
+      const float* bs = Bs + bufsel * SLAB + ti * 1024 + boff;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[j] = ld4(bs + 2 * j * 64);
+    };
+    auto split_col = [&](int u, Split8& f) __attribute__((always_inline)) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = bv[j][u];
+      split8(x, f);
+    };
+    // this chunk's share of the staging: a quarter of the filter chunk two ahead and one slot of the next slab into the idle buffer
+    // (tap slot 0's slots — positions 0..7 — in the first two chunks, the rest in the last: they are first read by the SECOND chunk
+    // of the next superchunk).  Seven loads, always.  o0 is this chunk's slot of the wave's three; they rotate with the chunks.
+    int o0 = my_ord[0], o1 = my_ord[1], o2 = my_ord[2];
+    auto batch = [&]() __attribute__((always_inline)) {
+      issue_a();
+      issue_slot(o0, lds_b + (bufsel ^ 1u) * (SLAB * 4u), slab_src, slot_desc(a_lo + B_r), sc + 1 < sc_end);
+      const int o = o0;
+      o0 = o1;
+      o1 = o2;
+      o2 = o;
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+      const int t1 = ti + 1, w = (t1 * 11) >> 5;   // w = 1 when the superchunk is complete
+      ti = t1 - 3 * w;
+      bufsel ^= (unsigned)w;
+      sc += w;
+      slab_next(w);
+      const int s1 = stage + 1, ws = (s1 * 11) >> 5;
+      stage = s1 - STA * ws;
+    };
+
+    // prologue: slab 0, filter chunks 0 and 1
+    {
+      const unsigned so = slot_desc(a_lo + B_r);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) issue_slot(my_ord[q], lds_b, slab_src, so, true);
+      slab_next(1);
+    }
+    issue_a();
+    issue_a();
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+    __syncthreads();
+
+    Split8 fa0[MT], fa1[MT], fb[2];
+    static_assert(NTC % 2 == 0, "column parity of fb is carried across chunks");
+    load_a(0, fa0);
+    read_b();
+    split_col(0, fb[0]);
+    // one chunk = one tap of the slab: column u's 6*MT MFMAs run with column u+1's split (and, under column 0, the staging issue) in
+    // their shadow; the chunk barrier sits in front of the LAST column, whose MFMAs cover the next chunk's LDS reads and the split of
+    // its column 0.
+    auto chunk = [&](Split8 (&fa)[MT], Split8 (&fan)[MT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u + 1 < NTC; ++u) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (u == 0) batch();
+        if (u == NTC - 2) advance();   // (the counters of the NEXT chunk, for the reads behind the barrier: stepped here, in the shadow)
+        split_col(u + 1, fb[(u + 1) & 1]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t][u] = split_mac(fa[t], fb[u & 1], acc[t][u]);
+#pragma unroll
+        for (int i = 0; i < 6 * MT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          if (u == 0 || u == NTC - 2) __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);
+        }
+      }
+      // the last column's split is complete HERE (the compiler otherwise sinks it towards its use, out of the MFMA shadow)
+      asm volatile("" ::"v"(fb[(NTC - 1) & 1].h), "v"(fb[(NTC - 1) & 1].m), "v"(fb[(NTC - 1) & 1].l));
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0x0077);   // vmcnt(7) lgkmcnt(0): everything this wave issued before this chunk's batch has landed
+      __syncthreads();                      // ... and every other wave's; every wave has read this chunk's A and slab slots out of LDS
+      load_a(stage, fan);
+      read_b();
+      split_col(0, fb[NTC & 1]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t][NTC - 1] = split_mac(fa[t], fb[(NTC - 1) & 1], acc[t][NTC - 1]);
+      // the slab reads first (the split of column 0 waits for them), the filter reads under the first MFMAs, the split under the rest
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+#pragma unroll
+      for (int i = 6; i < 6 * MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      }
+      asm volatile("" ::"v"(fb[NTC & 1].h), "v"(fb[NTC & 1].m), "v"(fb[NTC & 1].l));
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    int c = 0;
+    if (nchunks & 1) {
+      chunk(fa0, fa1);
+      c = 1;
+    } else {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) fa1[t] = fa0[t];
+    }
+    for (; c < nchunks; c += 2) {
+      chunk(fa1, fa0);
+      chunk(fa0, fa1);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);   // the last two batches (dump / free-stage loads) before the LDS is released
+  }
+
+  // ---- epilogue: gg_kernel's, with the unit column mapping (GGParams::patch) -------------------------------------------------
+  if (tsplit >= 0) {
+    float* pp = p.tail_partial + ((size_t)(L - p.tail_first) * p.tail_splits + tsplit) * (size_t)(ROWS * WC * CW);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        fvec v;
+#pragma unroll
+        for (int u = 0; u < NTC; ++u) v[u] = acc[t][u][reg];
+        *reinterpret_cast<fvec*>(pp + ((size_t)(t * 16 + reg) * NC + tid) * NTC) = v;
+      }
+    return;
+  }
+  gg_epilogue<1, WC, MT, CW, true>(p, acc, row_tile, col_tile, split, T.ncols, T.GX, T.G, T.dy0, T.dx0);
+}
+
+// gg_tail_fix_kernel for gpw_kernel's tile: the same four blocks per tail tile, each summing the tail_splits partial tiles of a quarter
+// of the accumulator registers in fixed order and running the normal epilogue on them — with the quarter a COMPILE-TIME constant per
+// branch: with 256 accumulator registers per lane the runtime range of gg_tail_fix_kernel indexes the array dynamically (2 KB of scratch).
+template <int PART>
+__device__ __forceinline__ void gpw_tail_fix_part(const GGParams& p, int tile) {
+  constexpr int WC = 4, MT = 4, CW = 128, NT = WC * 64, NTC = CW / 32, ROWS = MT * 32;
+  constexpr int reg_lo = PART * (16 / kTailFixParts), reg_hi = reg_lo + 16 / kTailFixParts;
+  using fvec = __attribute__((ext_vector_type(NTC))) float;
+  const int L = p.tail_first + tile;
+  const int tid = threadIdx.x;
+  f32x16 acc[MT][NTC];
+  const float* pp = p.tail_partial + (size_t)tile * p.tail_splits * (size_t)(ROWS * WC * CW);
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int reg = reg_lo; reg < reg_hi; ++reg) {
+      fvec v = *reinterpret_cast<const fvec*>(pp + ((size_t)(t * 16 + reg) * NT + tid) * NTC);
+      for (int sp = 1; sp < p.tail_splits; ++sp)
+        v += *reinterpret_cast<const fvec*>(pp + (size_t)sp * (ROWS * WC * CW) + ((size_t)(t * 16 + reg) * NT + tid) * NTC);
+#pragma unroll
+      for (int u = 0; u < NTC; ++u) acc[t][u][reg] = v[u];
+    }
+  gg_epilogue<1, WC, MT, CW, true>(p, acc, L % p.row_tiles, L / p.row_tiles, 0, p.ncols, p.GX, p.G, p.dy0, p.dx0, reg_lo, reg_hi);
+}
+__global__ __launch_bounds__(256) void gpw_tail_fix_kernel(const GGParams p) {
+  const int tile = blockIdx.x / kTailFixParts;
+  switch (blockIdx.x % kTailFixParts) {
+    case 0: gpw_tail_fix_part<0>(p, tile); break;
+    case 1: gpw_tail_fix_part<1>(p, tile); break;
+    case 2: gpw_tail_fix_part<2>(p, tile); break;
+    default: gpw_tail_fix_part<3>(p, tile); break;
+  }
+}
+
 namespace {
 
 int g_patch_mode = -1;
@@ -667,8 +1046,8 @@ int patch_slots(Kern kern, int threads, size_t lds) {
 }  // namespace
 
 // Can this gather (GGParams filled by conv_up_impl / conv_down_impl for ggp_kernel's tap-major pre-split path: KC > 0, apre) run on
-// gpp_kernel?  Fills the tap groups.  A tap row is cut into ssx groups of taps that are ssx apart (one group for a stride-1
-// gather): inside a group neighbouring pixels' taps coincide, slot i of pixel j+1 = slot i+1 of pixel j.
+// gpp_kernel / gpw_kernel?  Fills the tap groups.  A tap row is cut into ssx groups of taps that are ssx apart (one group for a
+// stride-1 gather): inside a group neighbouring pixels' taps coincide, slot i of pixel j+1 = slot i+1 of pixel j.
 bool patch_shape_ok(GGParams& p) {
   if (!patch_mode() || matrix_path() == 0 || p.KC <= 0 || p.KC % BK != 0) return false;
   if (p.N % 64 != 0 || p.GX < 4 || p.R <= 64) return false;
@@ -682,14 +1061,24 @@ bool patch_shape_ok(GGParams& p) {
     p.gb0[r] = p.dir > 0 ? r : r + (cnt - 1) * p.ssx;
   }
   if (p.ng == 1) { p.gcnt[1] = p.gcnt[0]; p.gb0[1] = p.gb0[0]; }
+  // gpw_kernel: 3-tap rows of a stride-1 gather; its 12 slots hold ONE wrap per tile: output rows of >= 8 pixels
+  if (patch_mode() == 3 && (p.ng != 1 || p.gcnt[0] != 3 || p.GX < kWideP)) return false;
   return true;
 }
 
-// The split of the filter bank and of the whole source tensor (C = p.KC channels of SH x SW x N) into planes, then the gather-GEMM
-// on them.  `op` / `flops` feed the kernel timers (algorithmic work of the call).
+// The split of the filter bank (and, for the planes build, of the whole source tensor: C = p.KC channels of SH x SW x N) into planes,
+// then the gather-GEMM on them.  `op` / `flops` feed the kernel timers (algorithmic work of the call).
 void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, const PatchBank& bank) {
-  constexpr int WR = 2, WC = 2, MT = 2, CW = 128;
-  constexpr int ROWS = WR * MT * 32;
+  constexpr int WR = 2, WC = 2, MT = 2, CW = 128;   // gpp_kernel
+  constexpr int ROWS = 128;                         // both kernels
+  static_assert(ROWS == WR * MT * 32, "row tile");
+  // CONVNET_GG_PATCH / convnet_hip_set_patch_mode: 1 = gpp_kernel on a raw fp32 slab, split by the consumers; 2 = gpp_kernel on bf16
+  // planes of the source tensor (one more pass); 3 = gpw_kernel (8 units x 128 rows, raw slab, no producer wave)
+  const int mode = patch_mode();
+  const bool wide = mode == 3, braw = mode != 2;
+  const int PU = wide ? kWideP : kPatchP;           // units per tile
+  const int TCOLS = PU * 64;                        // columns per tile
+  const int threads = wide ? 256 : WR * WC * 64 + 64;
   const int C = p.KC, HW = p.SH * p.SW, N = p.N, CB = C / BK;
   const size_t elems = (size_t)C * HW * N;
   const int RT = divup(p.R, ROWS);
@@ -701,8 +1090,6 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
     p.A = reinterpret_cast<const float*>(ap);
     p.apre = 1;
   }
-  // CONVNET_GG_PATCH: 1 (default) = raw fp32 slab, split by the consumers; 2 = bf16 planes of the source tensor (one more pass)
-  const bool braw = patch_mode() != 2;
   u32x4* planes = nullptr;
   if (!braw) {
     planes = static_cast<u32x4*>(workspace_planes(elems * 6));
@@ -717,14 +1104,16 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
   p.planes = planes;
   p.NP = N;
   p.ncols = 0;
-  p.row_tiles = divup(p.R, ROWS);
-  p.col_tiles = divup(p.IB * p.G, kPatchP);
+  p.row_tiles = RT;
+  p.col_tiles = divup(p.IB * p.G, PU);
   p.zero = zero_page();
   p.prio = CHIP_DIAG_KNOB("CONVNET_GPP_DIAG", 0);
   constexpr size_t lds_p = sizeof(float) * (3 * (6 * ROWS * 4) + 2 * (6 * 8 * 256)), lds_r = sizeof(float) * (3 * (6 * ROWS * 4) + 2 * (4 * 8 * 256));
+  constexpr size_t lds_w = sizeof(float) * (3 * (6 * ROWS * 4) + 2 * (kWideNS * 1024) + 1024);   // + the dump slot
   static const int slots_p = patch_slots(gpp_kernel<WR, WC, MT, CW, false>, WR * WC * 64 + 64, lds_p);
   static const int slots_r = patch_slots(gpp_kernel<WR, WC, MT, CW, true>, WR * WC * 64 + 64, lds_r);
-  const int slots = braw ? slots_r : slots_p;
+  static const int slots_w = patch_slots(gpw_kernel, 256, lds_w);
+  const int slots = wide ? slots_w : braw ? slots_r : slots_p;
   const int tiles = p.row_tiles * p.col_tiles;
   const int TYn = p.TYX / p.TX;
   const int nsc = CB * TYn * p.ng;                    // superchunks of a whole reduction
@@ -733,7 +1122,7 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
   // split-K by wave quantisation, as gg_launch_cfg; the unit of a K-range is the superchunk
   int splits = 1;
   if (dst_elems > 0 && kchunks >= 16) {
-    const double fl = 2.0 * ROWS * (WC * (double)CW) * (double)p.K;
+    const double fl = 2.0 * ROWS * (double)TCOLS * (double)p.K;
     double best_t = 1e30;
     for (int sp = 1; sp <= 16 && kchunks / sp >= 8 && nsc / sp >= 1; ++sp) {
       const double rounds = std::ceil(tiles * (double)sp / slots);
@@ -754,8 +1143,8 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
   p.tail_partial = nullptr;
   if (splits == 1 && dst_elems > 0 && tiles > slots && tiles % slots != 0 && kchunks >= 32) {
     const int full = (tiles / slots) * slots, rem = tiles - full;
-    const double tile_bytes = sizeof(float) * (double)ROWS * WC * CW;
-    const double t_round = 2.0 * ROWS * (WC * (double)CW) * (double)p.K / block_rate;
+    const double tile_bytes = sizeof(float) * (double)ROWS * TCOLS;
+    const double t_round = 2.0 * ROWS * (double)TCOLS * (double)p.K / block_rate;
     double best = 0.95;
     int best_s = 1;
     for (int s = 2; s <= 8 && kchunks / s >= 8; ++s) {
@@ -771,20 +1160,22 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
       p.tail_splits = divup(nsc, p.tail_cps);
       p.tail_tf8 = full / 8;
       p.tail_tt8 = divup(rem * p.tail_splits, 8);
-      p.tail_partial = static_cast<float*>(workspace(sizeof(float) * (size_t)rem * p.tail_splits * ROWS * WC * CW));
+      p.tail_partial = static_cast<float*>(workspace(sizeof(float) * (size_t)rem * p.tail_splits * ROWS * TCOLS));
     }
   }
   dim3 grid(p.tail_splits > 1 ? 8 * (p.tail_tf8 + p.tail_tt8) : ((tiles + 7) / 8) * 8, splits);
   static const GGClassTable kNone = {};
   {
-    KernelTimer timer(braw ? "gpp_kernel<2,2,2,128,raw>" : "gpp_kernel<2,2,2,128,planes>", op, flops, 0.0, 0.0);
-    if (braw) hipLaunchKernelGGL((gpp_kernel<WR, WC, MT, CW, true>), grid, dim3(WR * WC * 64 + 64), lds_r, stream(), p, kNone);
-    else hipLaunchKernelGGL((gpp_kernel<WR, WC, MT, CW, false>), grid, dim3(WR * WC * 64 + 64), lds_p, stream(), p, kNone);
+    KernelTimer timer(wide ? "gpw_kernel<128x512,raw>" : braw ? "gpp_kernel<2,2,2,128,raw>" : "gpp_kernel<2,2,2,128,planes>", op, flops, 0.0, 0.0);
+    if (wide) hipLaunchKernelGGL(gpw_kernel, grid, dim3(threads), lds_w, stream(), p, kNone);
+    else if (braw) hipLaunchKernelGGL((gpp_kernel<WR, WC, MT, CW, true>), grid, dim3(threads), lds_r, stream(), p, kNone);
+    else hipLaunchKernelGGL((gpp_kernel<WR, WC, MT, CW, false>), grid, dim3(threads), lds_p, stream(), p, kNone);
   }
   if (p.tail_splits > 1) {
     const int rem = tiles - p.tail_first;
-    KernelTimer timer("gg_tail_fix_kernel", op, 0.0, sizeof(float) * (double)rem * (p.tail_splits + 1) * ROWS * WC * CW);
-    hipLaunchKernelGGL((gg_tail_fix_kernel<WR, WC, MT, CW, true>), dim3(rem * kTailFixParts), dim3(WR * WC * 64), 0, stream(), p);
+    KernelTimer timer("gg_tail_fix_kernel", op, 0.0, sizeof(float) * (double)rem * (p.tail_splits + 1) * ROWS * TCOLS);
+    if (wide) hipLaunchKernelGGL(gpw_tail_fix_kernel, dim3(rem * kTailFixParts), dim3(256), 0, stream(), p);
+    else hipLaunchKernelGGL((gg_tail_fix_kernel<WR, WC, MT, CW, true>), dim3(rem * kTailFixParts), dim3(WR * WC * 64), 0, stream(), p);
   }
   if (splits > 1) gg_reduce_launch(p, dst_elems, splits, op);
 }
@@ -792,6 +1183,6 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
 }  // namespace chip
 
 extern "C" {
-void convnet_hip_set_patch_mode(int mode) { chip::g_patch_mode = mode < 0 ? 0 : mode > 2 ? 2 : mode; }
+void convnet_hip_set_patch_mode(int mode) { chip::g_patch_mode = mode < 0 ? 0 : mode > 3 ? 3 : mode; }
 int convnet_hip_get_patch_mode(void) { return chip::patch_mode(); }
 }

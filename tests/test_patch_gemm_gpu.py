@@ -1,10 +1,11 @@
-"""gpp_kernel (convnet_amd/csrc/patch_gemm.hip) — the patch-resident gather-GEMM on pre-split source planes that runs conv fprop /
+"""gpp_kernel / gpw_kernel (convnet_amd/csrc/patch_gemm.hip) — the patch-resident gather-GEMM on pre-split source planes that runs conv fprop /
 dgrad of the 3x3 and 5x5 layers on the default (bf16-split) matrix path — against the CPU oracle (the reference's conv_up /
 conv_down, cudamat_conv_gemm.cu:545-825) on geometries chosen for ITS mechanisms: tiles that wrap from one image row to the next,
 from one 64-image block to the next, the ragged last tile, tap groups of a stride-2 row, partial row tiles, border tap rows.
 Every case asserts that the patch kernel is what ran (convnet_hip_last_kernel_info), so a silent fallback cannot pass.
 Tolerance: the reference's own kernel-test metric, max|a-b| / mean|a+b| < 1e-4 (py/test_conv.py:382-392)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -124,3 +125,74 @@ def test_patch_modes_agree_with_ggp_kernel(hip):
     _lib.lib.convnet_hip_set_patch_mode(1)
     assert rel_err(outs[1], outs[0]) < 1e-5 and rel_err(outs[2], outs[0]) < 1e-5
     assert np.array_equal(outs[1], outs[2])   # raw and planes builds: identical operands, identical order
+
+
+# ---- gpw_kernel (patch mode 3: 128 rows x 8 units per block, four waves staging for themselves; 3 x 3 stride-1 gathers with output
+# rows >= 8 wide).  Written at the end of round 4 with the GPU budget spent: its control logic is checked on the CPU
+# (tests/test_patch_wide_cpu.py) but the kernel has not run on hardware yet, so these cases are opt-in until it has
+# (CONVNET_TEST_PATCH_WIDE=1; wrap the run in `timeout`).
+wide = pytest.mark.skipif(not os.environ.get("CONVNET_TEST_PATCH_WIDE"), reason="gpw_kernel not yet validated on hardware (CONVNET_TEST_PATCH_WIDE=1)")
+WIDE_FPROP = [
+    Geom(N=64, C=32, H=9, W=9, F=96, Ky=3, Kx=3, pady=1, padx=1),             # a wrap in almost every tile
+    Geom(N=128, C=80, H=13, W=13, F=144, Ky=3, Kx=3, pady=1, padx=1),          # conv3/4 grid, two image blocks, partial row tile, ragged last tile
+    Geom(N=64, C=16, H=10, W=10, F=72, Ky=3, Kx=3),                            # pad 0, 8-wide output rows
+    Geom(N=64, C=48, H=7, W=12, F=72, Ky=3, Kx=3, pady=1, padx=1),             # rectangular
+    Geom(N=64, C=32, H=11, W=11, F=96, Ky=3, Kx=3, pady=2, padx=2),            # whole tap rows outside the image
+    Geom(N=64, C=32, H=8, W=8, F=100, Ky=1, Kx=3, padx=1),                     # one tap row
+    Geom(N=256, C=384, H=13, W=13, F=384, Ky=3, Kx=3, pady=1, padx=1),         # conv4 itself: 254 tiles, 216 chunks each
+    Geom(N=256, C=192, H=13, W=13, F=256, Ky=3, Kx=3, pady=1, padx=1),         # 170 tiles: split-K
+]
+WIDE_DGRAD = [
+    Geom(N=64, C=96, H=9, W=9, F=32, Ky=3, Kx=3, pady=1, padx=1),
+    Geom(N=128, C=144, H=13, W=13, F=80, Ky=3, Kx=3, pady=1, padx=1),
+    Geom(N=64, C=128, H=13, W=13, F=48, Ky=3, Kx=3),                           # conv5 type: pad 0, 11 x 11 derivatives into 13 x 13
+    Geom(N=256, C=384, H=13, W=13, F=256, Ky=3, Kx=3, pady=1, padx=1),         # conv5's dgrad at full size
+]
+
+
+@pytest.fixture
+def wide_mode(hip):
+    from convnet_amd import _lib
+    _lib.lib.convnet_hip_set_patch_mode(3)
+    yield
+    _lib.lib.convnet_hip_set_patch_mode(1)
+
+
+@wide
+@pytest.mark.parametrize("g", WIDE_FPROP, ids=_id)
+def test_wide_fprop_vs_oracle(hip, wide_mode, g):
+    rng = np.random.default_rng(31)
+    x, w = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape())
+    for st in (0.0, 1.0):
+        t0 = rnd(rng, g.out_shape())
+        got = hip.conv_up(g, x, w, t0.copy(), st)
+        assert last_kernel() == "gpw_kernel(fprop)", last_kernel()
+        assert rel_err(got, oracle.port.conv_up(g, x, w, t0.copy(), st)) < TOL
+
+
+@wide
+@pytest.mark.parametrize("g", WIDE_DGRAD, ids=_id)
+def test_wide_dgrad_vs_oracle(hip, wide_mode, g):
+    rng = np.random.default_rng(32)
+    dy, w = rnd(rng, g.out_shape()), rnd(rng, g.filt_shape())
+    for st in (0.0, 1.0):
+        t0 = rnd(rng, g.in_shape())
+        got = hip.conv_down(g, dy, w, t0.copy(), st)
+        assert last_kernel() == "gpw_kernel(dgrad)", last_kernel()
+        assert rel_err(got, oracle.port.conv_down(g, dy, w, t0.copy(), st)) < TOL
+
+
+@wide
+def test_wide_agrees_with_gpp_raw(hip):
+    """Same operand splits, same six products, same order along k (cb, tap row, tap) — up to the split-K partition, which each kernel
+    picks for its own tile count: agreement to accumulation rounding."""
+    from convnet_amd import _lib
+    g = Geom(N=64, C=64, H=13, W=13, F=128, Ky=3, Kx=3, pady=1, padx=1)
+    rng = np.random.default_rng(33)
+    x, w = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape())
+    outs = []
+    for mode in (1, 3):
+        _lib.lib.convnet_hip_set_patch_mode(mode)
+        outs.append(hip.conv_up(g, x, w))
+    _lib.lib.convnet_hip_set_patch_mode(1)
+    assert rel_err(outs[1], outs[0]) < 1e-5

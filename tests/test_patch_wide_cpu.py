@@ -1,0 +1,247 @@
+"""gpw_kernel (convnet_amd/csrc/patch_gemm.hip, patch mode 3: 128 rows x 8 units per block, four waves that stage for themselves) —
+its control logic restated in Python and run against the CPU oracle; no GPU.  The kernel was written with the round's GPU budget
+spent, so this is the check it has had: the unit / slot bookkeeping (S, first-needed order, the three positions of each wave), the
+per-lane slot description, the arithmetic iterators (filter chunk pointer two chunks ahead, slab one superchunk ahead), the ring
+stages and slab buffers, and the rule each wave waits by (vmcnt(7): everything it issued before this chunk's seven loads).
+
+The model is adversarial about WHEN a load lands: once with every load landing the moment it is issued (a write into a region still
+being read shows up) and once with every load landing as late as the issuing wave's wait allows (a read before its data shows up).
+LDS starts as NaN, so anything read before it was written poisons the result."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import Geom
+
+P, NS, WAVES = 8, 12, 4
+NO_SLOT, ZERO_SLOT = -1, -2
+
+
+def run_tile(par, src, bank, col_tile, lazy):
+    """One block of gpw_kernel.  par: the GGParams fields the kernel reads; src [KC][SH][SW][N]; bank[q] = filter chunk q as a
+    [R][16] matrix (chunk q = cb*TYX + a*TX + b).  Returns {unit j: [R][64] accumulator}."""
+    G, GX, IB, N = par["G"], par["GX"], par["IB"], par["N"]
+    SH, SW, ssy, ssx, y0, x0, d = par["SH"], par["SW"], par["ssy"], par["ssx"], par["y0"], par["x0"], par["dir"]
+    TX, TYX, gb = par["TX"], par["TYX"], par["gb0"]
+    TYn, units = TYX // TX, IB * G
+    # ---- units
+    ok, ib, oy, ox, S = [], [], [], [], []
+    for j in range(P):
+        U = col_tile * P + j
+        ok.append(U < units)
+        ib.append(U // G if ok[j] else 0)
+        m = U - ib[j] * G if ok[j] else 0
+        oy.append(m // GX)
+        ox.append(m - oy[j] * GX)
+        S.append(0 if j == 0 else S[j - 1] + (0 if not ok[j] else 1 if (ib[j] == ib[j - 1] and oy[j] == oy[j - 1]) else 3))
+    ys0 = [oy[j] * ssy + y0 for j in range(P) if ok[j]]
+    ys_f, ys_l = min(ys0), max(ys0)
+    # first-needed order -> my_ord[wave][step]; per-"lane" slot description
+    my_ord = [[-1] * 3 for _ in range(WAVES)]
+    slot = {}
+    seen, no = set(), 0
+    for i in range(3):
+        for j in range(P):
+            sl = S[j] + i
+            if ok[j] and sl < NS and sl not in seen:
+                seen.add(sl)
+                my_ord[no % 4][no // 4] = sl
+                no += 1
+            if ok[j]:
+                assert sl < NS
+                slot[sl] = (oy[j] * ssy + y0, ox[j] * ssx + x0 + d * gb + i * ssx, ib[j] * 64)
+    assert no <= 12
+
+    def slot_desc(a):
+        out = {}
+        for s, (sy, sx, sib) in slot.items():
+            ys = sy + d * a
+            out[s] = (ys, sx, sib) if (0 <= sx < SW and 0 <= ys < SH) else ZERO_SLOT
+        return out
+    # ---- reduction range (whole K, border tap rows skipped)
+    if d > 0:
+        a_lo, a_hi = max(0, -ys_l), min(TYn - 1, SH - 1 - ys_f)
+    else:
+        a_lo, a_hi = max(0, ys_f - (SH - 1)), min(TYn - 1, ys_l)
+    nrow = max(0, a_hi - a_lo + 1)
+    nsc = (par["KC"] // 16) * nrow
+    sc_beg, sc_end, nchunks = 0, nsc, 3 * nsc
+    R = bank[0].shape[0]
+    acc = {j: np.zeros((R, 64)) for j in range(P) if ok[j]}
+    if nchunks == 0:
+        return acc
+    # ---- LDS and in-flight loads
+    A_lds = [np.full((R, 16), np.nan) for _ in range(3)]
+    B_lds = [[np.full((16, 64), np.nan) for _ in range(NS)] for _ in range(2)]
+    inflight = [[] for _ in range(WAVES)]   # per wave: (landing closure, batch id)
+
+    def issue(w, fn, batch_id):
+        if lazy:
+            inflight[w].append((fn, batch_id))
+        else:
+            fn()
+
+    def wait_all_but_batch(w, batch_id):   # vmcnt(7): everything issued before this chunk's batch has landed
+        keep = []
+        for fn, b in inflight[w]:
+            if b < batch_id:
+                fn()
+            else:
+                keep.append((fn, b))
+        inflight[w] = keep
+
+    dstep = d * ssx
+    a_tap, a_row_x, a_cbs_x = dstep, TX - 3 * dstep, TYX - (a_hi - a_lo + 1) * TX
+    # every wave carries the same iterators; one copy here, the loads tagged with the wave that issues them
+    st = dict(a_q=(sc_beg // nrow) * TYX + (a_lo + sc_beg % nrow) * TX + gb, A_i=0, A_r=sc_beg % nrow, A_left=nchunks,
+              f=[0, 1, 2], B_r=sc_beg % nrow, B_cb=sc_beg // nrow)
+
+    def issue_a(batch_id):
+        q, stage = st["a_q"], st["f"][0]
+        assert 0 <= q < len(bank)
+        for w in range(WAVES):   # a quarter of the chunk each: rows stand in for the 3 KB pieces
+            rows = slice(w * R // 4, (w + 1) * R // 4) if R % 4 == 0 else (slice(0, R) if w == 0 else slice(0, 0))
+
+            def land(rows=rows, q=q, stage=stage):
+                A_lds[stage][rows] = bank[q][rows]
+            issue(w, land, batch_id)
+        st["f"] = st["f"][1:] + st["f"][:1]
+        st["A_left"] -= 1
+        more = 1 if st["A_left"] > 0 else 0
+        i1 = st["A_i"] + 1
+        w1 = (i1 * 11) >> 5
+        st["A_i"] = i1 - 3 * w1
+        r1 = st["A_r"] + w1
+        w2 = 1 if r1 >= nrow else 0
+        st["A_r"] = r1 - nrow * w2
+        st["a_q"] += more * (a_tap + w1 * a_row_x + w2 * a_cbs_x)
+
+    def slab_next(step):
+        r1 = st["B_r"] + step
+        w = 1 if r1 >= nrow else 0
+        st["B_r"] = r1 - nrow * w
+        st["B_cb"] += w
+
+    def issue_slot(w, sl, buf, cb, desc, enable, batch_id):
+        if not enable or sl < 0 or sl not in desc:
+            return   # dump region
+        dsc = desc[sl]
+
+        def land(sl=sl, buf=buf, cb=cb, dsc=dsc):
+            if dsc == ZERO_SLOT:
+                B_lds[buf][sl] = np.zeros((16, 64))
+            else:
+                ys, xs, sib = dsc
+                B_lds[buf][sl] = src[16 * cb:16 * cb + 16, ys, xs, sib:sib + 64].astype(np.float64)
+        issue(w, land, batch_id)
+
+    # prologue (batch ids -3, -2): slab 0, filter chunks 0 and 1; vmcnt(0)
+    desc0 = slot_desc(a_lo + st["B_r"])
+    for w in range(WAVES):
+        for q in range(3):
+            issue_slot(w, my_ord[w][q], 0, st["B_cb"], desc0, True, -3)
+    slab_next(1)
+    issue_a(-2)
+    issue_a(-2)
+    for w in range(WAVES):
+        wait_all_but_batch(w, 10 ** 9)
+    # consumer state
+    stage, bufsel, ti, sc = 0, 0, 0, sc_beg
+    o = [list(my_ord[w]) for w in range(WAVES)]
+
+    def read_chunk():   # load_a + read_b right behind a barrier
+        a = A_lds[stage].copy()
+        b = {j: B_lds[bufsel][S[j] + ti].copy() for j in acc}
+        return a, b
+    cur = read_chunk()
+    for c in range(nchunks):
+        # batch(): in the shadow of column 0
+        issue_a(c)
+        desc = slot_desc(a_lo + st["B_r"])
+        for w in range(WAVES):
+            issue_slot(w, o[w][0], bufsel ^ 1, st["B_cb"], desc, sc + 1 < sc_end, c)
+            o[w] = o[w][1:] + o[w][:1]
+        # MFMAs of this chunk (operands were read behind the previous barrier)
+        a, b = cur
+        for j in acc:
+            acc[j] += a @ b[j]
+        # advance(), wait, barrier, reads of the next chunk
+        t1 = ti + 1
+        wv = (t1 * 11) >> 5
+        ti = t1 - 3 * wv
+        bufsel ^= wv
+        sc += wv
+        slab_next(wv)
+        stage = (stage + 1) % 3
+        for w in range(WAVES):
+            wait_all_but_batch(w, c)
+        cur = read_chunk() if c + 1 < nchunks else None
+    return acc
+
+
+def conv_by_tiles(g, x, w, dgrad, lazy):
+    """fprop of g (or the input gradient of a stride-1 g) assembled from gpw_kernel tiles; x / w in the oracle's layouts."""
+    if not dgrad:
+        C, F = g.C, g.F
+        par = dict(G=g.My * g.Mx, GX=g.Mx, IB=g.N // 64, N=g.N, SH=g.H, SW=g.W, ssy=g.sy, ssx=g.sx, y0=-g.pady, x0=-g.padx, dir=1,
+                   TX=g.Kx, TYX=g.Ky * g.Kx, gb0=0, KC=C)
+        wl = w.reshape(C, g.Ky, g.Kx, F)
+        bank = [wl[16 * cb:16 * cb + 16, a, b, :].T.astype(np.float64) for cb in range(C // 16) for a in range(g.Ky) for b in range(g.Kx)]
+        out = np.zeros((F, g.My, g.Mx, g.N))
+        GXo = g.Mx
+    else:
+        C, F = g.C, g.F   # rows = input channels, reduction over filters
+        par = dict(G=g.H * g.W, GX=g.W, IB=g.N // 64, N=g.N, SH=g.My, SW=g.Mx, ssy=1, ssx=1, y0=g.pady, x0=g.padx, dir=-1,
+                   TX=g.Kx, TYX=g.Ky * g.Kx, gb0=g.Kx - 1, KC=F)
+        wl = w.reshape(C, g.Ky, g.Kx, F)
+        bank = [wl[:, a, b, 16 * fb:16 * fb + 16].astype(np.float64) for fb in range(F // 16) for a in range(g.Ky) for b in range(g.Kx)]
+        out = np.zeros((C, g.H, g.W, g.N))
+        GXo = g.W
+    units = par["IB"] * par["G"]
+    for ct in range((units + P - 1) // P):
+        acc = run_tile(par, x, bank, ct, lazy)
+        for j, v in acc.items():
+            U = ct * P + j
+            ib, m = divmod(U, par["G"])
+            out[:, m // GXo, m % GXo, ib * 64:ib * 64 + 64] = v
+    return out
+
+
+FPROP = [
+    Geom(N=64, C=32, H=9, W=9, F=8, Ky=3, Kx=3, pady=1, padx=1),     # 9-wide rows: a wrap in almost every tile
+    Geom(N=128, C=16, H=13, W=13, F=8, Ky=3, Kx=3, pady=1, padx=1),  # conv3/4 grid, image-block wrap, ragged last tile (338 units)
+    Geom(N=64, C=16, H=10, W=10, F=8, Ky=3, Kx=3),                   # pad 0: 8-wide output rows, every tile is one row
+    Geom(N=64, C=16, H=7, W=12, F=8, Ky=3, Kx=3, pady=1, padx=1),    # rectangular
+    Geom(N=64, C=16, H=11, W=11, F=8, Ky=3, Kx=3, pady=2, padx=2),   # padding wider than one tap: whole tap rows outside
+    Geom(N=64, C=16, H=8, W=8, F=8, Ky=1, Kx=3, padx=1),             # one tap row
+]
+DGRAD = [
+    Geom(N=64, C=8, H=9, W=9, F=32, Ky=3, Kx=3, pady=1, padx=1),
+    Geom(N=128, C=8, H=13, W=13, F=16, Ky=3, Kx=3, pady=1, padx=1),
+    Geom(N=64, C=8, H=13, W=13, F=16, Ky=3, Kx=3),                   # conv5 type: pad 0, 11 x 11 derivatives into 13 x 13
+]
+_id = lambda g: f"N{g.N}C{g.C}H{g.H}W{g.W}F{g.F}k{g.Ky}x{g.Kx}p{g.pady}"  # noqa: E731
+
+
+@pytest.mark.parametrize("lazy", [False, True], ids=["eager", "lazy"])
+@pytest.mark.parametrize("g", FPROP, ids=_id)
+def test_wide_tile_schedule_fprop(g, lazy):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(g.in_shape()).astype(np.float32)
+    w = rng.standard_normal(g.filt_shape()).astype(np.float32)
+    ref = oracle.port.conv_up(g, x, w).astype(np.float64)
+    got = conv_by_tiles(g, x, w, False, lazy)
+    assert not np.isnan(got).any()
+    assert np.abs(got - ref).max() < 2e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("lazy", [False, True], ids=["eager", "lazy"])
+@pytest.mark.parametrize("g", DGRAD, ids=_id)
+def test_wide_tile_schedule_dgrad(g, lazy):
+    rng = np.random.default_rng(6)
+    dy = rng.standard_normal(g.out_shape()).astype(np.float32)
+    w = rng.standard_normal(g.filt_shape()).astype(np.float32)
+    ref = oracle.port.conv_down(g, dy, w).astype(np.float64)
+    got = conv_by_tiles(g, dy, w, True, lazy)
+    assert not np.isnan(got).any()
+    assert np.abs(got - ref).max() < 2e-4 * np.abs(ref).max()
