@@ -917,6 +917,23 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
     load_a(0, fa0);
     read_b();
     split_col(0, fb[0]);
+    // A column's 6*MT MFMAs, the six products of split_mac in its order but the MT row tiles innermost: with ONE wave per SIMD no other
+    // wave fills the wait of an MFMA for the one before it on the same accumulator; this way four independent ones sit between.
+    // (Per accumulator the order of the six is split_mac's: same bits.)
+    auto mac_col = [&](const Split8 (&fa)[MT], const Split8& b, int u) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t][u] = mma_bf16(fa[t].m, b.m, acc[t][u]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t][u] = mma_bf16(fa[t].h, b.l, acc[t][u]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t][u] = mma_bf16(fa[t].l, b.h, acc[t][u]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t][u] = mma_bf16(fa[t].h, b.m, acc[t][u]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t][u] = mma_bf16(fa[t].m, b.h, acc[t][u]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t][u] = mma_bf16(fa[t].h, b.h, acc[t][u]);
+    };
     // one chunk = one tap of the slab: column u's 6*MT MFMAs run with column u+1's split (and, under column 0, the staging issue) in
     // their shadow; the chunk barrier sits in front of the LAST column, whose MFMAs cover the next chunk's LDS reads and the split of
     // its column 0.
@@ -927,8 +944,7 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
         if (u == 0) batch();
         if (u == NTC - 2) advance();   // (the counters of the NEXT chunk, for the reads behind the barrier: stepped here, in the shadow)
         split_col(u + 1, fb[(u + 1) & 1]);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) acc[t][u] = split_mac(fa[t], fb[u & 1], acc[t][u]);
+        mac_col(fa, fb[u & 1], u);
 #pragma unroll
         for (int i = 0; i < 6 * MT; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -944,8 +960,7 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
       load_a(stage, fan);
       read_b();
       split_col(0, fb[NTC & 1]);
-#pragma unroll
-      for (int t = 0; t < MT; ++t) acc[t][NTC - 1] = split_mac(fa[t], fb[(NTC - 1) & 1], acc[t][NTC - 1]);
+      mac_col(fa, fb[(NTC - 1) & 1], NTC - 1);
       // the slab reads first (the split of column 0 waits for them), the filter reads under the first MFMAs, the split under the rest
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll

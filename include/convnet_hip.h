@@ -112,8 +112,11 @@ int convnet_hip_get_matrix_path(void);
  * arithmetic, same results to rounding — a schedule choice, for A/B runs and tests):
  *   0: ggp_kernel — one output pixel x 256 images per block, every tap a fresh fetch of the source;
  *   1: gpp_kernel, raw  — 4 neighbouring pixels x 64 images per block; the source pixels of a whole tap row staged once, as fp32;
- *   2: gpp_kernel, planes — the same tile reading the source from bf16 planes written by one extra pass (act_planes_kernel).
- * Initial value: environment CONVNET_GG_PATCH, else 1. */
+ *   2: gpp_kernel, planes — the same tile reading the source from bf16 planes written by one extra pass (act_planes_kernel);
+ *   3: gpw_kernel — 8 neighbouring pixels x 64 images x 128 rows per block, raw fp32 source, the block's four waves stage for
+ *      themselves (3x3 stride-1 gathers with output rows >= 8 pixels; other shapes fall back to mode 0).  EXPERIMENTAL: written after
+ *      the last hardware run of its round, checked on the CPU only (tests/test_patch_wide_cpu.py).
+ * Initial value: environment CONVNET_GG_PATCH, else 0. */
 void convnet_hip_set_patch_mode(int mode);
 int convnet_hip_get_patch_mode(void);
 const char* get_last_cuda_error(void);               /* cudamat.cuh:109 */
