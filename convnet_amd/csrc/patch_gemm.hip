@@ -744,6 +744,13 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
       }
   }
   const bool xin_l = valid_l && (unsigned)sx_l < (unsigned)SW;
+  // Integer division has no scalar form: everything derived from U / G, m / GX lives in VGPRs although it is wave-uniform, and drags
+  // the loop's bookkeeping onto the vector ALU.  What the loop keeps goes back to SGPRs here.
+  auto sgpr = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+#pragma unroll
+  for (int q = 0; q < 3; ++q) my_ord[q] = sgpr(my_ord[q]);
+  ys_f = sgpr(ys_f);
+  ys_l = sgpr(ys_l);
 
   // ---- reduction range in superchunks (16-channel block cb, tap row a); three chunks (taps) each --------------------------------
   const int TX = T.TX, TYX = T.TYX, TYn = TYX / TX;
@@ -762,6 +769,7 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
     sc_end = min(nsc_all, sc_beg + cps);
   }
   const int nchunks = 3 * (sc_end - sc_beg);
+  const int cb_beg = nrow > 0 ? sgpr(sc_beg / nrow) : 0, r_beg = nrow > 0 ? sgpr(sc_beg % nrow) : 0;   // first superchunk: channel block, tap row - a_lo
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   f32x16 acc[MT][NTC];
@@ -795,13 +803,19 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
     // (as differences: a select between two captured variables becomes a load through a selected ADDRESS and sends the whole closure to scratch)
     const ptrdiff_t a_tap = (ptrdiff_t)a_chunk_bytes * dstep, a_row_x = (ptrdiff_t)a_chunk_bytes * (TX - 3 * dstep),
                     a_cbs_x = (ptrdiff_t)a_chunk_bytes * (TYX - (a_hi - a_lo + 1) * TX);
-    const char* a_ptr = abase0 + a_chunk_bytes * (size_t)((sc_beg / nrow) * TYX + (a_lo + sc_beg % nrow) * TX + gb);   // wave-uniform
+    const char* a_ptr = abase0 + a_chunk_bytes * (size_t)(cb_beg * TYX + (a_lo + r_beg) * TX + gb);   // wave-uniform
     // counters as plain integer arithmetic (0/1 flags, masks): booleans with && / ?: come back from the optimizer as branches
-    int A_i = 0, A_r = sc_beg % nrow, A_left = nchunks;   // tap slot, tap row - a_lo, chunks not yet issued
+    int A_i = 0, A_r = r_beg, A_left = nchunks;   // tap slot, tap row - a_lo, chunks not yet issued
     unsigned lds_f0 = lds_a, lds_f1 = lds_a + A_STAGE * 4u, lds_f2 = lds_a + 2u * A_STAGE * 4u;   // the ring stage to fill next first
-    auto issue_a = [&]() __attribute__((always_inline)) {
-      const char* const ap = uniform_ptr(a_ptr);
-      lds_dma3(a_lane, ap, ap, ap, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_f0));
+    // (in two parts, so that a chunk can place them in different steps: the address into SGPRs, then the loads and the stepping)
+    const char* a_cur = nullptr;
+    unsigned a_lds = 0;
+    auto issue_a_addr = [&]() __attribute__((always_inline)) {
+      a_cur = uniform_ptr(a_ptr);
+      a_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_f0);
+    };
+    auto issue_a_go = [&]() __attribute__((always_inline)) { lds_dma3(a_lane, a_cur, a_cur, a_cur, a_lds); };
+    auto issue_a_step = [&]() __attribute__((always_inline)) {
       const unsigned f = lds_f0;
       lds_f0 = lds_f1;
       lds_f1 = lds_f2;
@@ -815,10 +829,15 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
       const ptrdiff_t d = a_tap + (-(ptrdiff_t)w1 & a_row_x) + (-(ptrdiff_t)w2 & a_cbs_x);   // next tap / + next row / + next block
       a_ptr += -(ptrdiff_t)more & d;
     };
+    auto issue_a = [&]() __attribute__((always_inline)) {
+      issue_a_addr();
+      issue_a_go();
+      issue_a_step();
+    };
     // slab iterator, one superchunk ahead: tap row and the source pointer of its channel block
     int B_r = A_r;   // tap row - a_lo
     const size_t cb_bytes = 16 * ch_bytes;   // one 16-channel block of the source
-    const char* slab_src = rawsrc + (size_t)(sc_beg / nrow) * cb_bytes;
+    const char* slab_src = rawsrc + (size_t)cb_beg * cb_bytes;
     auto slab_next = [&](int step) __attribute__((always_inline)) {   // step: 0 / 1
       const int r1 = B_r + step, w = 1 - (int)((unsigned)(r1 - nrow) >> 31);
       B_r = r1 - nrow * w;
@@ -834,22 +853,41 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
       return valid_l ? o1 : kNoSlot;
     };
     const ptrdiff_t d4 = (ptrdiff_t)(4 * ch_bytes) - 1024;   // four channel planes on, minus the 1 KB the immediate offset adds
-    // slot sl (< 0: none) of the slab described by soff from source block `src` into the slab buffer at LDS address ldbuf
-    auto issue_slot = [&](int sl, unsigned ldbuf, const char* src, unsigned soff, bool enable) __attribute__((always_inline)) {
-      const int slc = sl < 0 ? 0 : sl;
-      const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)soff, slc);
-      // (the two flags through readfirstlane: as plain booleans the compiler keeps them as lane masks and moves the address selects,
-      // all wave-uniform, to the vector ALU — the staging instruction wants them in SGPRs)
-      const bool none = __builtin_amdgcn_readfirstlane((int)(!enable || sl < 0 || so == kNoSlot)) != 0;
-      const bool real = __builtin_amdgcn_readfirstlane((int)(!none && so != kZeroSlot)) != 0;
-      const char* const rbase = src + (size_t)so * 4;   // wave-uniform: k-row 0 of the slot
-      const char* const base = real ? rbase : zero_page;
-      const ptrdiff_t st = real ? d4 : (ptrdiff_t)-1024;
-      const unsigned voff = real ? lane_off_raw : 0u;
+    // slot sl (< 0: none) of the slab described by soff from source block `src` into the slab buffer at LDS address ldbuf — in three
+    // parts for the same reason: what kind of load it is, its four addresses, the loads
+    struct SlotIssue {
+      unsigned so, voff, ld, real;   // real: 0 / 1
+      const char *p0, *p1, *p2, *p3;
+    } si;
+    // 0 / 1 flags and masks instead of booleans (see the counters above): none = nobody reads the slot, real = it is inside the image
+    auto slot_kind = [&](int sl, unsigned ldbuf, unsigned soff, int enable) __attribute__((always_inline)) {
+      const unsigned neg = (unsigned)sl >> 31;
+      const int slc = sl & ~(-(int)neg);                                     // max(sl, 0)
+      si.so = (unsigned)__builtin_amdgcn_readlane((int)soff, slc);
+      const unsigned is_no = 1u - min(si.so + 1u, 1u), is_zero = 1u - min(si.so + 2u, 1u);   // so == kNoSlot, so == kZeroSlot
+      const unsigned none = (1u - (unsigned)enable) | neg | is_no;
+      si.real = (1u - none) & (1u - is_zero);
       const unsigned ldr = ldbuf + (unsigned)slc * 4096u;
-      const unsigned ld = none ? lds_dump : ldr;
-      lds_dma4(voff, uniform_ptr(base), uniform_ptr(base + st), uniform_ptr(base + 2 * st), uniform_ptr(base + 3 * st),
-               (unsigned)__builtin_amdgcn_readfirstlane((int)ld));
+      si.ld = ldr ^ ((ldr ^ lds_dump) & (0u - none));                        // none ? dump : slot
+      si.voff = lane_off_raw & (0u - si.real);
+    };
+    auto slot_addr = [&](const char* src) __attribute__((always_inline)) {
+      const ptrdiff_t m = -(ptrdiff_t)si.real;
+      const char* const rbase = src + (size_t)si.so * 4;   // wave-uniform: k-row 0 of the slot
+      const char* const base = zero_page + ((rbase - zero_page) & m);
+      const ptrdiff_t st = (ptrdiff_t)-1024 + ((d4 + 1024) & m);
+      si.p0 = uniform_ptr(base);
+      si.p1 = uniform_ptr(base + st);
+      si.p2 = uniform_ptr(base + 2 * st);
+      si.p3 = uniform_ptr(base + 3 * st);
+    };
+    auto slot_go = [&]() __attribute__((always_inline)) {
+      lds_dma4(si.voff, si.p0, si.p1, si.p2, si.p3, (unsigned)__builtin_amdgcn_readfirstlane((int)si.ld));
+    };
+    auto issue_slot = [&](int sl, unsigned ldbuf, const char* src, unsigned soff, int enable) __attribute__((always_inline)) {
+      slot_kind(sl, ldbuf, soff, enable);
+      slot_addr(src);
+      slot_go();
     };
 
     // ================================ consumer state ================================
@@ -872,19 +910,12 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
 #pragma unroll
       for (int j = 0; j < 8; ++j) bv[j] = ld4(bs + 2 * j * 64);
     };
-    auto split_col = [&](int u, Split8& f) __attribute__((always_inline)) {
-      float x[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = bv[j][u];
-      split8(x, f);
-    };
     // this chunk's share of the staging: a quarter of the filter chunk two ahead and one slot of the next slab into the idle buffer
     // (tap slot 0's slots — positions 0..7 — in the first two chunks, the rest in the last: they are first read by the SECOND chunk
     // of the next superchunk).  Seven loads, always.  o0 is this chunk's slot of the wave's three; they rotate with the chunks.
     int o0 = my_ord[0], o1 = my_ord[1], o2 = my_ord[2];
-    auto batch = [&]() __attribute__((always_inline)) {
-      issue_a();
-      issue_slot(o0, lds_b + (bufsel ^ 1u) * (SLAB * 4u), slab_src, slot_desc(a_lo + B_r), sc + 1 < sc_end);
+    auto next_slot_kind = [&]() __attribute__((always_inline)) {
+      slot_kind(o0, lds_b + (bufsel ^ 1u) * (SLAB * 4u), slot_desc(a_lo + B_r), (int)((unsigned)(sc + 1 - sc_end) >> 31));   // sc + 1 < sc_end
       const int o = o0;
       o0 = o1;
       o1 = o2;
@@ -904,7 +935,7 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
     {
       const unsigned so = slot_desc(a_lo + B_r);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) issue_slot(my_ord[q], lds_b, slab_src, so, true);
+      for (int q = 0; q < 3; ++q) issue_slot(my_ord[q], lds_b, slab_src, so, 1);
       slab_next(1);
     }
     issue_a();
@@ -914,68 +945,102 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
 
     Split8 fa0[MT], fa1[MT], fb[2];
     static_assert(NTC % 2 == 0, "column parity of fb is carried across chunks");
-    load_a(0, fa0);
-    read_b();
-    split_col(0, fb[0]);
-    // A column's 6*MT MFMAs, the six products of split_mac in its order but the MT row tiles innermost: with ONE wave per SIMD no other
-    // wave fills the wait of an MFMA for the one before it on the same accumulator; this way four independent ones sit between.
-    // (Per accumulator the order of the six is split_mac's: same bits.)
-    auto mac_col = [&](const Split8 (&fa)[MT], const Split8& b, int u) __attribute__((always_inline)) {
+    // A chunk is written out as 4 columns x 6 STEPS of MT = 4 MFMAs, each step fenced (sched_barrier) and carrying its share of the
+    // other work by hand: the scheduler's group patterns hold inside a step of this size, not over a whole column (it left 20-50
+    // VALU in one lump at region borders: ~12 % of a chunk with the matrix pipe idle).  A step = one of the six products of split_mac,
+    // in its order, over the four row tiles: four independent accumulators between two MFMAs on the same one (with ONE wave per SIMD no
+    // other wave fills that wait; per accumulator the order of the six is split_mac's — same bits).
+    auto mac_step = [&](auto K, const Split8 (&fa)[MT], const Split8& b, int u) __attribute__((always_inline)) {
+      constexpr int k = decltype(K)::value;
 #pragma unroll
-      for (int t = 0; t < MT; ++t) acc[t][u] = mma_bf16(fa[t].m, b.m, acc[t][u]);
+      for (int t = 0; t < MT; ++t) {
+        const u32x4& av = k == 0 || k == 4 ? fa[t].m : k == 2 ? fa[t].l : fa[t].h;   // (m,m) (h,l) (l,h) (h,m) (m,h) (h,h)
+        const u32x4& bw = k == 0 || k == 3 ? b.m : k == 1 ? b.l : b.h;
+        acc[t][u] = mma_bf16(av, bw, acc[t][u]);
+      }
 #pragma unroll
-      for (int t = 0; t < MT; ++t) acc[t][u] = mma_bf16(fa[t].h, b.l, acc[t][u]);
-#pragma unroll
-      for (int t = 0; t < MT; ++t) acc[t][u] = mma_bf16(fa[t].l, b.h, acc[t][u]);
-#pragma unroll
-      for (int t = 0; t < MT; ++t) acc[t][u] = mma_bf16(fa[t].h, b.m, acc[t][u]);
-#pragma unroll
-      for (int t = 0; t < MT; ++t) acc[t][u] = mma_bf16(fa[t].m, b.h, acc[t][u]);
-#pragma unroll
-      for (int t = 0; t < MT; ++t) acc[t][u] = mma_bf16(fa[t].h, b.h, acc[t][u]);
+      for (int i = 0; i < MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     };
-    // one chunk = one tap of the slab: column u's 6*MT MFMAs run with column u+1's split (and, under column 0, the staging issue) in
-    // their shadow; the chunk barrier sits in front of the LAST column, whose MFMAs cover the next chunk's LDS reads and the split of
-    // its column 0.
+    // pair q of split8 for column u of the slab values in bv
+    auto split_pair = [&](int u, int q, Split8& f) __attribute__((always_inline)) {
+      const float x0 = bv[2 * q][u], x1 = bv[2 * q + 1][u];
+      const unsigned H = pk_bf16(x0, x1);
+      const float r0 = x0 - __uint_as_float(H << 16), r1 = x1 - __uint_as_float(H & 0xffff0000u);
+      const unsigned M = pk_bf16(r0, r1);
+      const float s0 = r0 - __uint_as_float(M << 16), s1 = r1 - __uint_as_float(M & 0xffff0000u);
+      f.h[q] = H;
+      f.m[q] = M;
+      f.l[q] = pk_bf16(s0, s1);
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    using K3 = std::integral_constant<int, 3>;
+    using K4 = std::integral_constant<int, 4>;
+    using K5 = std::integral_constant<int, 5>;
+    // one chunk = one tap of the slab.  Columns 0..2: the split of the next column in steps 0..3 (a pair each), the staging issue
+    // under column 0, the counters of the next chunk under column 2; the chunk barrier; column 3 with the next chunk's LDS reads in
+    // steps 0-1 and the split of its column 0 in steps 2..5.
     auto chunk = [&](Split8 (&fa)[MT], Split8 (&fan)[MT]) __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u + 1 < NTC; ++u) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (u == 0) batch();
-        if (u == NTC - 2) advance();   // (the counters of the NEXT chunk, for the reads behind the barrier: stepped here, in the shadow)
-        split_col(u + 1, fb[(u + 1) & 1]);
-        mac_col(fa, fb[u & 1], u);
-#pragma unroll
-        for (int i = 0; i < 6 * MT; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-          if (u == 0 || u == NTC - 2) __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);
-        }
+        Split8& fn = fb[(u + 1) & 1];
+        const Split8& fc = fb[u & 1];
+        split_pair(u + 1, 0, fn);
+        if (u == 0) issue_a_addr();
+        mac_step(K0{}, fa, fc, u);
+        split_pair(u + 1, 1, fn);
+        if (u == 0) issue_a_go();
+        mac_step(K1{}, fa, fc, u);
+        split_pair(u + 1, 2, fn);
+        mac_step(K2{}, fa, fc, u);
+        split_pair(u + 1, 3, fn);
+        mac_step(K3{}, fa, fc, u);
+        // steps 4 and 5 carry no split: the staging bookkeeping (column 0: which load the slot is, its addresses; column 1: the slot's
+        // loads, the filter iterator) and the counters of the NEXT chunk for the reads behind the barrier (column 2)
+        if (u == 0) next_slot_kind();
+        if (u == 1) slot_go();
+        if (u == NTC - 2) advance();
+        mac_step(K4{}, fa, fc, u);
+        if (u == 0) slot_addr(slab_src);
+        if (u == 1) issue_a_step();
+        mac_step(K5{}, fa, fc, u);
       }
       // the last column's split is complete HERE (the compiler otherwise sinks it towards its use, out of the MFMA shadow)
       asm volatile("" ::"v"(fb[(NTC - 1) & 1].h), "v"(fb[(NTC - 1) & 1].m), "v"(fb[(NTC - 1) & 1].l));
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(0x0077);   // vmcnt(7) lgkmcnt(0): everything this wave issued before this chunk's batch has landed
       __syncthreads();                      // ... and every other wave's; every wave has read this chunk's A and slab slots out of LDS
-      load_a(stage, fan);
-      read_b();
-      split_col(0, fb[NTC & 1]);
-      mac_col(fa, fb[(NTC - 1) & 1], NTC - 1);
-      // the slab reads first (the split of column 0 waits for them), the filter reads under the first MFMAs, the split under the rest
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      {
+        const Split8& fc = fb[(NTC - 1) & 1];
+        Split8& fn = fb[NTC & 1];
+        read_b();
+        mac_step(K0{}, fa, fc, NTC - 1);
+        load_a(stage, fan);
+        mac_step(K1{}, fa, fc, NTC - 1);
+        split_pair(0, 0, fn);
+        mac_step(K2{}, fa, fc, NTC - 1);
+        split_pair(0, 1, fn);
+        mac_step(K3{}, fa, fc, NTC - 1);
+        split_pair(0, 2, fn);
+        mac_step(K4{}, fa, fc, NTC - 1);
+        split_pair(0, 3, fn);
+        mac_step(K5{}, fa, fc, NTC - 1);
+        asm volatile("" ::"v"(fn.h), "v"(fn.m), "v"(fn.l));   // (as above: complete here)
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int i = 6; i < 6 * MT; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-      }
-      asm volatile("" ::"v"(fb[NTC & 1].h), "v"(fb[NTC & 1].m), "v"(fb[NTC & 1].l));
-      __builtin_amdgcn_sched_barrier(0);
     };
+    load_a(0, fa0);
+    read_b();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split_pair(0, q, fb[0]);
     int c = 0;
     if (nchunks & 1) {
       chunk(fa0, fa1);
