@@ -95,6 +95,8 @@ def _load():
     sig("convnet_hip_get_matrix_path", I)
     sig("convnet_hip_set_patch_mode", None, I)
     sig("convnet_hip_get_patch_mode", I)
+    sig("convnet_hip_set_wgrad_tile", None, I)
+    sig("convnet_hip_get_wgrad_tile", I)
     sig("get_last_cuda_error", ctypes.c_char_p)
     sig("cuda_set_device", I, I)
     sig("cuda_sync_threads", None)

@@ -409,6 +409,42 @@ void filter_planes_gk_launch(const float* W, void* out, int F, int K, int KP, in
 bool patch_shape_ok(GGParams& p);
 void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, const PatchBank& bank);
 
+// -------------------------------------------------------------------------------------------------
+// wg_kernel / wgw_kernel: dW[k, f] over the (pixel, image) reduction (gather_gemm.hip, wgrad_wide.hip).
+// -------------------------------------------------------------------------------------------------
+struct WGParams {
+  const float* src;   // layer input  (N, SH*SW*C)
+  const float* dout;  // output deriv (N, M*F), M = GY*GX
+  float* dst;         // dW (F, K)  column-major: dst[f + F*k]
+  float* partial;     // [splits][K (+1 with bias_dst)][F]
+  const float* zero;  // zero page for out-of-range loads; floats [32, 36) of the page hold 1.0f
+  float* bias_dst;    // nullable: db (1, F).  The bias gradient is the dW row of a virtual tap k == K whose input is
+                      // the constant 1 (db[f] = sum over pixels, images of dout) — it rides in a padding row of the tile.
+  int K, F, N;
+  int GX, M;
+  int TX, TYX;
+  int SH, SW;
+  int ssy, ssx, y0, x0;
+  int nchunk;         // ceil(N/32) image chunks per pixel
+  int chunks_total;   // M*nchunk
+  int chunks_per_split;
+  int splits;
+  int k_tiles, f_tiles;
+  float scaleTargets, scaleOutput;
+  int prio;           // issue priority scheme (wg_prio_mode()): 0 none, 1 MFMA phase high, 2 staging phase high
+  int wide;           // the 128 x 128 tile's write-out goes through LDS and leaves as 16-byte stores (F % 4 == 0, 16-byte aligned targets)
+};
+
+constexpr int WG_NB = 32;          // images per stage
+constexpr int WG_PITCH = WG_NB + 4;  // conflict-free ds_read_b128 across rows
+
+// slab reduce of the weight-gradient kernels (gather_gemm.hip)
+__global__ void wg_reduce_group_kernel(float* __restrict__ stage, const float* __restrict__ partial, size_t total, int splits, int per);
+__global__ void wg_reduce_kernel(float* __restrict__ dst, float* __restrict__ dst2, const float* __restrict__ partial, size_t total, size_t main,
+                                 int splits, float scaleTargets, float scaleOutput);
+// wgw_kernel (wgrad_wide.hip): takes the launch and returns true when the wide tile is selected (convnet_hip_set_wgrad_tile) and applies
+bool wgw_try(WGParams& p, bool vec, bool split_products, const char* op, double flops, double exec);
+
 // split-K second stage (gather_gemm.hip): dst = scaleTargets*dst + sum of the slabs, with the fused bias / ReLU / mask options of p
 void gg_reduce_launch(const GGParams& p, size_t dst_elems, int splits, const char* op);
 

@@ -989,32 +989,7 @@ __global__ void filter_tapmajor_kernel(const float* __restrict__ W, float* __res
 // -------------------------------------------------------------------------------------------------
 // wg_kernel: dW[k, f] over (pixel, image) reduction.
 // -------------------------------------------------------------------------------------------------
-struct WGParams {
-  const float* src;   // layer input  (N, SH*SW*C)
-  const float* dout;  // output deriv (N, M*F), M = GY*GX
-  float* dst;         // dW (F, K)  column-major: dst[f + F*k]
-  float* partial;     // [splits][K (+1 with bias_dst)][F]
-  const float* zero;  // zero page for out-of-range loads; floats [32, 36) of the page hold 1.0f
-  float* bias_dst;    // nullable: db (1, F).  The bias gradient is the dW row of a virtual tap k == K whose input is
-                      // the constant 1 (db[f] = sum over pixels, images of dout) — it rides in a padding row of the tile.
-  int K, F, N;
-  int GX, M;
-  int TX, TYX;
-  int SH, SW;
-  int ssy, ssx, y0, x0;
-  int nchunk;         // ceil(N/32) image chunks per pixel
-  int chunks_total;   // M*nchunk
-  int chunks_per_split;
-  int splits;
-  int k_tiles, f_tiles;
-  float scaleTargets, scaleOutput;
-  int prio;           // issue priority scheme (wg_prio_mode()): 0 none, 1 MFMA phase high, 2 staging phase high
-  int wide;           // the 128 x 128 tile's write-out goes through LDS and leaves as 16-byte stores (F % 4 == 0, 16-byte aligned targets)
-};
-
-constexpr int WG_NB = 32;          // images per stage
-constexpr int WG_PITCH = WG_NB + 4;  // conflict-free ds_read_b128 across rows
-
+// (WGParams, WG_NB, WG_PITCH: gather_gemm.h — shared with wgw_kernel, wgrad_wide.hip)
 // TS = MFMA tile edge: 32 (v_mfma_f32_32x32x2, 16 accumulator registers per tile) or 16 (v_mfma_f32_16x16x4, 4 per
 // tile; same FLOP/clk).  The 16-wide tiles let a 160 x 96 problem (conv1: 147 taps x 96 filters) split evenly
 // over 2x2 waves (80 x 48 each), which no arrangement of 32-wide tiles can: the 5-wave 32x32 config ran at 70
@@ -1815,6 +1790,7 @@ void wg_launch_cfg(WGParams& p, bool vec) {
 }
 
 void wg_launch(WGParams& p, bool vec) {
+  if (wgw_try(p, vec, vec && wg_split_mode(), t_op, t_flops, t_exec)) return;   // the wide tile (wgrad_wide.hip), when selected
   // filter tile: fewest padded filters among 128/96/64/32; k tile 128, or 160 when that pads less.
   int ft = 128, pad = divup(p.F, 128) * 128;
   const int cands[3] = {96, 64, 32};

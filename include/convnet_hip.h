@@ -119,6 +119,13 @@ int convnet_hip_get_matrix_path(void);
  * Initial value: environment CONVNET_GG_PATCH, else 0. */
 void convnet_hip_set_patch_mode(int mode);
 int convnet_hip_get_patch_mode(void);
+/* Which kernel runs the weight gradients (conv wgrad, FC wgrad) on matrix path 1 — a schedule choice like the one above:
+ *   0: wg_kernel — 128 x 128 tile, four waves of 64 x 64, two blocks per CU;
+ *   1: wgw_kernel — 256 x 256 (or 256 x 192) tile, four waves of 128 x 128, one block per CU (N % 32 == 0, K >= 256, F >= 192; other
+ *      shapes stay on wg_kernel).  EXPERIMENTAL: written after the last hardware run of its round; its schedule is checked at compile time.
+ * Initial value: environment CONVNET_WG_TILE, else 0. */
+void convnet_hip_set_wgrad_tile(int mode);
+int convnet_hip_get_wgrad_tile(void);
 const char* get_last_cuda_error(void);               /* cudamat.cuh:109 */
 int cuda_set_device(int deviceId);                   /* cudamat.cuh:116 */
 void cuda_sync_threads(void);                        /* cudamat.cuh:123 — synchronises the current stream */
