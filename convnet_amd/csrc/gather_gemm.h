@@ -438,10 +438,9 @@ struct WGParams {
 constexpr int WG_NB = 32;          // images per stage
 constexpr int WG_PITCH = WG_NB + 4;  // conflict-free ds_read_b128 across rows
 
-// slab reduce of the weight-gradient kernels (gather_gemm.hip)
-__global__ void wg_reduce_group_kernel(float* __restrict__ stage, const float* __restrict__ partial, size_t total, int splits, int per);
-__global__ void wg_reduce_kernel(float* __restrict__ dst, float* __restrict__ dst2, const float* __restrict__ partial, size_t total, size_t main,
-                                 int splits, float scaleTargets, float scaleOutput);
+// slab reduce of the weight-gradient kernels (gather_gemm.hip): dst (and the fused bias row) = scaleTargets*dst + scaleOutput * sum of
+// the `splits` slabs of `total` floats in p.partial, in fixed order; two levels when groups > 1 (stage area behind the slabs)
+void wg_reduce_launch(const WGParams& p, size_t total, int splits, int groups, const char* op);
 // wgw_kernel (wgrad_wide.hip): takes the launch and returns true when the wide tile is selected (convnet_hip_set_wgrad_tile) and applies
 bool wgw_try(WGParams& p, bool vec, bool split_products, const char* op, double flops, double exec);
 

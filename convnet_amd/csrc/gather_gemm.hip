@@ -1677,6 +1677,23 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
 
 }  // namespace
 
+void wg_reduce_launch(const WGParams& p, size_t total, int splits, int groups, const char* op) {   // (wgw_kernel's; wg_launch_cfg carries its own copy)
+  KernelTimer timer("wg_reduce_kernel", op, 0.0, sizeof(float) * (double)total * (splits + 1));
+  size_t nb = (total + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  const float* slabs = p.partial;
+  int nslabs = splits;
+  if (groups > 1) {
+    float* stage = p.partial + (size_t)splits * total;
+    const int per = divup(splits, groups);
+    hipLaunchKernelGGL(wg_reduce_group_kernel, dim3((unsigned)nb, divup(splits, per)), dim3(256), 0, stream(), stage, p.partial, total, splits, per);
+    slabs = stage;
+    nslabs = divup(splits, per);
+  }
+  hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream(), p.dst, p.bias_dst, slabs, total, (size_t)p.K * p.F, nslabs,
+                     p.scaleTargets, p.scaleOutput);
+}
+
 void gg_reduce_launch(const GGParams& p, size_t dst_elems, int splits, const char* op) {
   KernelTimer timer("gg_reduce_kernel", op, 0.0, sizeof(float) * (double)dst_elems * (splits + 1));
   size_t nb = (dst_elems + 255) / 256;

@@ -478,22 +478,7 @@ void wgw_launch(WGParams& p, const char* op, double flops, double exec) {
     KernelTimer timer(NTL == 4 ? "wgw_kernel<256x256,split>" : "wgw_kernel<256x192,split>", op, flops, 0.0, exec);
     hipLaunchKernelGGL(wgw_kernel<NTL>, grid, block, lds, stream(), p);
   }
-  if (splits > 1) {
-    KernelTimer timer("wg_reduce_kernel", op, 0.0, sizeof(float) * (double)total * (splits + 1));
-    size_t nb = (total + 255) / 256;
-    if (nb > 4096) nb = 4096;
-    const float* slabs = p.partial;
-    int nslabs = splits;
-    if (groups > 1) {
-      float* stage = p.partial + (size_t)splits * total;
-      const int per = divup(splits, groups);
-      hipLaunchKernelGGL(wg_reduce_group_kernel, dim3((unsigned)nb, divup(splits, per)), dim3(256), 0, stream(), stage, p.partial, total, splits, per);
-      slabs = stage;
-      nslabs = divup(splits, per);
-    }
-    hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream(), p.dst, p.bias_dst, slabs, total, (size_t)p.K * p.F, nslabs,
-                       p.scaleTargets, p.scaleOutput);
-  }
+  if (splits > 1) wg_reduce_launch(p, total, splits, groups, op);
 }
 
 }  // namespace
