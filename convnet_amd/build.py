@@ -34,7 +34,8 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
     objdir = os.path.join(HERE, "lib", "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(SRC, "common.h"), os.path.join(SRC, "gather_gemm.h"), os.path.join(HERE, "..", "include", "convnet_hip.h")]
+    headers = [os.path.join(SRC, "common.h"), os.path.join(SRC, "gather_gemm.h"), os.path.join(SRC, "wgrad_wide_schedule.h"),
+               os.path.join(HERE, "..", "include", "convnet_hip.h")]
     objs, procs = [], []
     for s in SOURCES:
         src = os.path.join(SRC, s)
