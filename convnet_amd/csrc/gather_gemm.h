@@ -137,6 +137,26 @@ __device__ __forceinline__ void lds_dma3(unsigned voff, const char* s0, const ch
                ::"v"(voff), "s"(s0), "s"(s1), "s"(s2), "s"(lds)
                : "memory", "m0");
 }
+// The same groups for SGPR operands that may have been written by a VALU instruction (v_readfirstlane: uniform_ptr) right in front of the
+// statement: a vector-memory instruction reading such an SGPR needs five wait states, and the compiler does not pad what is inside an
+// asm string.  (ggp_kernel's / gpp_kernel's producers compute their bases with scalar instructions and use the plain forms above.)
+__device__ __forceinline__ void lds_dma4_rfl(unsigned voff, const char* s0, const char* s1, const char* s2, const char* s3, unsigned lds) {
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %0, %1\n\t"
+               "global_load_lds_dwordx4 %0, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %0, %3 offset:2048\n\t"
+               "global_load_lds_dwordx4 %0, %4 offset:3072"
+               ::"v"(voff), "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(lds)
+               : "memory", "m0");
+}
+__device__ __forceinline__ void lds_dma3_rfl(unsigned voff, const char* s0, const char* s1, const char* s2, unsigned lds) {
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %0, %1\n\t"
+               "global_load_lds_dwordx4 %0, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %0, %3 offset:2048"
+               ::"v"(voff), "s"(s0), "s"(s1), "s"(s2), "s"(lds)
+               : "memory", "m0");
+}
 __device__ __forceinline__ void lds_dma2(unsigned voff, const char* s0, const char* s1, unsigned lds) {
   asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
                "global_load_lds_dwordx4 %0, %1\n\t"

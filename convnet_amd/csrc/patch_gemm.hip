@@ -814,7 +814,7 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
       a_cur = uniform_ptr(a_ptr);
       a_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_f0);
     };
-    auto issue_a_go = [&]() __attribute__((always_inline)) { lds_dma3(a_lane, a_cur, a_cur, a_cur, a_lds); };
+    auto issue_a_go = [&]() __attribute__((always_inline)) { lds_dma3_rfl(a_lane, a_cur, a_cur, a_cur, a_lds); };
     auto issue_a_step = [&]() __attribute__((always_inline)) {
       const unsigned f = lds_f0;
       lds_f0 = lds_f1;
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
       si.p3 = uniform_ptr(base + 3 * st);
     };
     auto slot_go = [&]() __attribute__((always_inline)) {
-      lds_dma4(si.voff, si.p0, si.p1, si.p2, si.p3, (unsigned)__builtin_amdgcn_readfirstlane((int)si.ld));
+      lds_dma4_rfl(si.voff, si.p0, si.p1, si.p2, si.p3, (unsigned)__builtin_amdgcn_readfirstlane((int)si.ld));
     };
     auto issue_slot = [&](int sl, unsigned ldbuf, const char* src, unsigned soff, int enable) __attribute__((always_inline)) {
       slot_kind(sl, ldbuf, soff, enable);
