@@ -163,7 +163,7 @@ def wide_mode(hip):
 def test_wide_fprop_vs_oracle(hip, wide_mode, g):
     rng = np.random.default_rng(31)
     x, w = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape())
-    for st in (0.0, 1.0):
+    for st in ((0.0,) if g.N * g.C * g.F > 10 ** 7 else (0.0, 1.0)):   # (the full-size layers: one pass of the CPU oracle)
         t0 = rnd(rng, g.out_shape())
         got = hip.conv_up(g, x, w, t0.copy(), st)
         assert last_kernel() == "gpw_kernel(fprop)", last_kernel()
@@ -175,7 +175,7 @@ def test_wide_fprop_vs_oracle(hip, wide_mode, g):
 def test_wide_dgrad_vs_oracle(hip, wide_mode, g):
     rng = np.random.default_rng(32)
     dy, w = rnd(rng, g.out_shape()), rnd(rng, g.filt_shape())
-    for st in (0.0, 1.0):
+    for st in ((0.0,) if g.N * g.C * g.F > 10 ** 7 else (0.0, 1.0)):
         t0 = rnd(rng, g.in_shape())
         got = hip.conv_down(g, dy, w, t0.copy(), st)
         assert last_kernel() == "gpw_kernel(dgrad)", last_kernel()

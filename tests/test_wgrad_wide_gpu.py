@@ -70,7 +70,7 @@ def test_wide_wgrad_vs_oracle(hip, wide, g):
     from convnet_amd import _lib
     rng = np.random.default_rng(41)
     x, dy = rnd(rng, g.in_shape()), rnd(rng, g.out_shape())
-    for st, so in ((0.0, 1.0), (1.0, 0.5)):
+    for st, so in (((0.0, 1.0),) if g.N * g.C * g.F > 10 ** 7 else ((0.0, 1.0), (1.0, 0.5))):   # (full-size layers: one pass of the CPU oracle)
         t0 = rnd(rng, g.filt_shape())
         _lib.profile_enable(True)
         got = hip.conv_outp(g, x, dy, t0.copy(), st, so)

@@ -2,18 +2,18 @@
 # First hardware run of gpw_kernel (patch mode 3) and wgw_kernel (wgrad tile 1, §2.2b): parity, then the same-call A/B
 # against the default kernels.
 # One gpurun call, every leg under its own timeout (a hang must not become a strike):
-#   gpurun --timeout 900 -- 'bash tools/wide_check.sh'
+#   gpurun --timeout 1500 -- 'bash tools/wide_check.sh'
 # Stops after the parity leg if that fails; results under gpurun_out/wide_check/.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/wide_check
 mkdir -p "$O"
 cd "$R"
 echo "== parity (CONVNET_TEST_PATCH_WIDE=1) =="
-CONVNET_TEST_PATCH_WIDE=1 timeout 300 python -m pytest tests/test_patch_gemm_gpu.py -k "wide" -x -q > "$O/parity.log" 2>&1
+CONVNET_TEST_PATCH_WIDE=1 timeout 420 python -m pytest tests/test_patch_gemm_gpu.py -k "wide" -x -q > "$O/parity.log" 2>&1
 rc=$?
 tail -5 "$O/parity.log"
 if [ $rc -ne 0 ]; then echo "gpw parity leg rc=$rc: its A/B legs are skipped"; GPW=0; else GPW=3; fi
-CONVNET_TEST_WGRAD_WIDE=1 timeout 300 python -m pytest tests/test_wgrad_wide_gpu.py -x -q > "$O/parity_wgw.log" 2>&1
+CONVNET_TEST_WGRAD_WIDE=1 timeout 420 python -m pytest tests/test_wgrad_wide_gpu.py -x -q > "$O/parity_wgw.log" 2>&1
 rc=$?
 tail -5 "$O/parity_wgw.log"
 if [ $rc -ne 0 ]; then echo "wgw parity leg rc=$rc: its A/B legs are skipped"; WGW=0; else WGW=1; fi
