@@ -60,6 +60,15 @@ def _same_kernel(bench_name, prof_name):
             return n.split("::")[-1], []
         return n[:n.index("<")].split("::")[-1], n[n.index("<") + 1:n.rindex(">")].split(",")
     wb, wa = parse(bench_name)
+    # the opt-in wide kernels: "gpw_kernel<128x512,split,raw>" is not a template (its own tail-fix kernel is "gpw_tail_fix_kernel");
+    # "wgw_kernel<256x192,split>" / "<256x256,split>" are wgw_kernel<3> / <4>; "gpp_kernel<2,2,2,128,split,raw|planes>" is <2,2,2,128,BRAW>
+    flat = prof_name.replace(" ", "")
+    if wb == "gpw_kernel":
+        return "gpw_kernel(" in flat or flat.endswith("gpw_kernel")
+    if wb == "wgw_kernel":
+        return ("wgw_kernel<3>" in flat and "256x192" in wa) or ("wgw_kernel<4>" in flat and "256x256" in wa)
+    if wb == "gpp_kernel":
+        return ("gpp_kernel<2,2,2,128,true>" in flat and "raw" in wa) or ("gpp_kernel<2,2,2,128,false>" in flat and "planes" in wa)
     fb, fa = parse(prof_name)
     nums = [a for a in wa if a.isdigit()]
     if wb != fb or fa[:len(nums)] != nums:
