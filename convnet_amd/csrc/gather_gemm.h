@@ -157,6 +157,16 @@ __device__ __forceinline__ void lds_dma3_rfl(unsigned voff, const char* s0, cons
                ::"v"(voff), "s"(s0), "s"(s1), "s"(s2), "s"(lds)
                : "memory", "m0");
 }
+// ONE piece, for streams that place their pieces between MFMAs one at a time (a piece costs the issuing wave ~60 cycles, back to back
+// they stack: MI355X_MICROARCH.md): piece J of a group whose M0 base is `lds` and whose source j is passed with 1024*j already subtracted.
+template <int J>
+__device__ __forceinline__ void lds_dma_piece_rfl(unsigned voff, const char* s, unsigned lds) {
+  static_assert(J >= 0 && J < 4, "immediate offset");
+  if constexpr (J == 0) asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(s), "s"(lds) : "memory", "m0");
+  if constexpr (J == 1) asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(s), "s"(lds) : "memory", "m0");
+  if constexpr (J == 2) asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(s), "s"(lds) : "memory", "m0");
+  if constexpr (J == 3) asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(s), "s"(lds) : "memory", "m0");
+}
 __device__ __forceinline__ void lds_dma2(unsigned voff, const char* s0, const char* s1, unsigned lds) {
   asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
                "global_load_lds_dwordx4 %0, %1\n\t"

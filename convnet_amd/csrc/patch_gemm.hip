@@ -814,7 +814,8 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
       a_cur = uniform_ptr(a_ptr);
       a_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_f0);
     };
-    auto issue_a_go = [&]() __attribute__((always_inline)) { lds_dma3_rfl(a_lane, a_cur, a_cur, a_cur, a_lds); };
+    auto issue_a_go = [&]() __attribute__((always_inline)) { lds_dma3_rfl(a_lane, a_cur, a_cur, a_cur, a_lds); };   // (prologue)
+    auto issue_a_piece = [&](auto J) __attribute__((always_inline)) { lds_dma_piece_rfl<decltype(J)::value>(a_lane, a_cur, a_lds); };
     auto issue_a_step = [&]() __attribute__((always_inline)) {
       const unsigned f = lds_f0;
       lds_f0 = lds_f1;
@@ -881,8 +882,12 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
       si.p2 = uniform_ptr(base + 2 * st);
       si.p3 = uniform_ptr(base + 3 * st);
     };
-    auto slot_go = [&]() __attribute__((always_inline)) {
+    auto slot_go = [&]() __attribute__((always_inline)) {   // (prologue)
       lds_dma4_rfl(si.voff, si.p0, si.p1, si.p2, si.p3, (unsigned)__builtin_amdgcn_readfirstlane((int)si.ld));
+    };
+    auto slot_piece = [&](auto J) __attribute__((always_inline)) {
+      constexpr int j = decltype(J)::value;
+      lds_dma_piece_rfl<j>(si.voff, j == 0 ? si.p0 : j == 1 ? si.p1 : j == 2 ? si.p2 : si.p3, (unsigned)__builtin_amdgcn_readfirstlane((int)si.ld));
     };
     auto issue_slot = [&](int sl, unsigned ldbuf, const char* src, unsigned soff, int enable) __attribute__((always_inline)) {
       slot_kind(sl, ldbuf, soff, enable);
@@ -993,24 +998,30 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
       for (int u = 0; u + 1 < NTC; ++u) {
         Split8& fn = fb[(u + 1) & 1];
         const Split8& fc = fb[u & 1];
+        // The seven staging loads go out ONE per step (a piece costs the issuing wave ~60 cycles; back to back they stack): the filter
+        // chunk's three under column 0, the slot's four under column 1.  Steps 4 and 5 carry no split: the staging bookkeeping (column
+        // 0: which load the slot is, its addresses; column 1: the filter iterator) and the counters of the NEXT chunk (column 2).
         split_pair(u + 1, 0, fn);
         if (u == 0) issue_a_addr();
+        if (u == 1) slot_piece(K0{});
         mac_step(K0{}, fa, fc, u);
         split_pair(u + 1, 1, fn);
-        if (u == 0) issue_a_go();
+        if (u == 0) issue_a_piece(K0{});
+        if (u == 1) slot_piece(K1{});
         mac_step(K1{}, fa, fc, u);
         split_pair(u + 1, 2, fn);
+        if (u == 0) issue_a_piece(K1{});
+        if (u == 1) slot_piece(K2{});
         mac_step(K2{}, fa, fc, u);
         split_pair(u + 1, 3, fn);
+        if (u == 0) issue_a_piece(K2{});
+        if (u == 1) slot_piece(K3{});
         mac_step(K3{}, fa, fc, u);
-        // steps 4 and 5 carry no split: the staging bookkeeping (column 0: which load the slot is, its addresses; column 1: the slot's
-        // loads, the filter iterator) and the counters of the NEXT chunk for the reads behind the barrier (column 2)
         if (u == 0) next_slot_kind();
-        if (u == 1) slot_go();
+        if (u == 1) issue_a_step();
         if (u == NTC - 2) advance();
         mac_step(K4{}, fa, fc, u);
         if (u == 0) slot_addr(slab_src);
-        if (u == 1) issue_a_step();
         mac_step(K5{}, fa, fc, u);
       }
       // the last column's split is complete HERE (the compiler otherwise sinks it towards its use, out of the MFMA shadow)
