@@ -1,6 +1,7 @@
 // Shared device helpers of the gather-GEMM translation units (gather_gemm.hip, patch_gemm.hip): launch parameter blocks, the
 // exact bf16 three-way split (Split8), the tile selection and the block-tile write-out.  gfx950 only.
 #pragma once
+#include <cstring>
 #include <type_traits>
 
 #include "common.h"
@@ -105,6 +106,21 @@ struct GGClassTable {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// The LDS byte address of a pointer into the block's dynamic shared memory (what M0 and the ds instructions take), and the
+// address-space pointer types of the staging builtin.  CONVNET_EMU: the kernels compiled as host code and run on the CPU
+// (tests/emu/hip/hip_runtime.h — test infrastructure for kernels that have not been on hardware yet); LDS is an ordinary array there.
+#ifndef CONVNET_EMU
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lds_ptr_t)p; }
+#else
+extern float smem[];   // every kernel's `extern __shared__ float smem[]`
+typedef void* lds_ptr_t;
+typedef const void* gbl_ptr_t;
+inline unsigned lds_addr(const void* p) { return (unsigned)(reinterpret_cast<const char*>(p) - reinterpret_cast<const char*>(smem)); }
+inline char* lds_ptr(unsigned a) { return reinterpret_cast<char*>(smem) + a; }
+#endif
+
 // LDS-DMA staging pieces of a producer wave, written out: `global_load_lds_dwordx4 v_off, s[base] offset:imm` — a wave-uniform
 // 64-bit base in SGPRs plus a 32-bit per-lane byte offset, M0 (the LDS destination) written ONCE for up to four 1 KB pieces whose
 // destinations are 1 KB apart (the immediate offset applies to both addresses, so source j is passed as s_j with its own 1024*j
@@ -120,6 +136,7 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
   const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
   return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
 }
+#ifndef CONVNET_EMU
 __device__ __forceinline__ void lds_dma4(unsigned voff, const char* s0, const char* s1, const char* s2, const char* s3, unsigned lds) {
   asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\t"
                "global_load_lds_dwordx4 %0, %1\n\t"
@@ -178,6 +195,29 @@ __device__ __forceinline__ void lds_dma1(unsigned voff, const char* s0, unsigned
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(s0), "s"(lds) : "memory", "m0");
 }
 
+// 16 bytes per lane to an LDS byte address (the producer's zero fill)
+__device__ __forceinline__ void lds_store16(unsigned addr, u32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+// "this Split8 is complete HERE": an empty statement that uses its three registers (the compiler otherwise sinks a split towards its use)
+#define CHIP_PIN_SPLIT8(f) asm volatile("" ::"v"((f).h), "v"((f).m), "v"((f).l))
+#else   // CONVNET_EMU: the same data movement as an immediate copy — piece j: 16 bytes per lane from s_j + 1024*j + voff to lds + 1024*j + 16*lane
+inline void emu_piece(unsigned voff, const char* s, unsigned lds, int j) {
+  std::memcpy(lds_ptr(lds + 1024u * j) + 16 * emu::lane_id(), s + 1024 * j + voff, 16);
+}
+inline void lds_dma4(unsigned voff, const char* s0, const char* s1, const char* s2, const char* s3, unsigned lds) {
+  emu_piece(voff, s0, lds, 0); emu_piece(voff, s1, lds, 1); emu_piece(voff, s2, lds, 2); emu_piece(voff, s3, lds, 3);
+}
+inline void lds_dma3(unsigned voff, const char* s0, const char* s1, const char* s2, unsigned lds) {
+  emu_piece(voff, s0, lds, 0); emu_piece(voff, s1, lds, 1); emu_piece(voff, s2, lds, 2);
+}
+inline void lds_dma4_rfl(unsigned voff, const char* s0, const char* s1, const char* s2, const char* s3, unsigned lds) { lds_dma4(voff, s0, s1, s2, s3, lds); }
+inline void lds_dma3_rfl(unsigned voff, const char* s0, const char* s1, const char* s2, unsigned lds) { lds_dma3(voff, s0, s1, s2, lds); }
+template <int J>
+inline void lds_dma_piece_rfl(unsigned voff, const char* s, unsigned lds) { emu_piece(voff, s, lds, J); }
+inline void lds_dma2(unsigned voff, const char* s0, const char* s1, unsigned lds) { emu_piece(voff, s0, lds, 0); emu_piece(voff, s1, lds, 1); }
+inline void lds_dma1(unsigned voff, const char* s0, unsigned lds) { emu_piece(voff, s0, lds, 0); }
+inline void lds_store16(unsigned addr, u32x4 v) { std::memcpy(lds_ptr(addr), &v, 16); }
+#define CHIP_PIN_SPLIT8(f) ((void)0)
+#endif
 // compile-time loop: f(integral_constant<int, I>) for I in [B, E) — keeps register-array indices constant
 template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F&& f) {

@@ -248,8 +248,6 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 2) void gpp_kernel(const GGParams
     nchunks = (nsc - n1) * gc0 + n1 * gc1;
   }
 
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
   if (wave == WR * WC) {
     // ================================ producer wave ================================
@@ -290,7 +288,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 2) void gpp_kernel(const GGParams
     auto issue_a = [&](int stage) __attribute__((always_inline)) {
       const int b = (A_g ? gbase1 : gbase0) + A_i * dir * ssx;
       const char* abase = abase0 + a_chunk_bytes * (size_t)(A_cb * TYX + A_a * TX + b);   // wave-uniform
-      const unsigned lda0 = (unsigned)(size_t)(lds_ptr_t)(As + stage * A_STAGE);
+      const unsigned lda0 = lds_addr(As + stage * A_STAGE);
 #pragma unroll
       for (int it = 0; it < NA; it += 4) {
         lds_dma4(a_lane, abase, abase, abase, abase, lda0 + 1024u * it);
@@ -348,7 +346,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 2) void gpp_kernel(const GGParams
     // slots [S0, S1) of a slab; slot s lands at LDS offset PS*s KB (planes: regions q = plane*2 + k-group 1 KB apart, as in memory;
     // raw: k-rows 256 B apart).  Returns the number of loads issued (PS per in-image slot).
     const size_t cb_bytes = BRAW ? 16 * ch_bytes : (size_t)SH * SW * IBn * 6144;   // one 16-channel block of the source
-    const unsigned zero_lds = (unsigned)(size_t)(lds_ptr_t)Bs + (unsigned)lane * 16u;
+    const unsigned zero_lds = lds_addr(Bs) + (unsigned)lane * 16u;
     // Issue order of a slab's slots: first the (up to four) slots tap slot 0 reads, S[j]; then S[j] + 1, then S[j] + 2.  The first
     // four must have landed when the superchunk starts; the rest is first read by its SECOND chunk, so it may be issued as late as
     // the last chunk of the superchunk before: every chunk of a 3-tap superchunk then carries two slots (12 pieces) of the next
@@ -387,17 +385,17 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 2) void gpp_kernel(const GGParams
           const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
           for (int q = 0; q < PS; ++q)
-            asm volatile("ds_write_b128 %0, %1" ::"v"(zero_lds + (unsigned)((buf * SLAB + 256 * (PS * sl + q)) * 4)), "v"(z) : "memory");
+            lds_store16(zero_lds + (unsigned)((buf * SLAB + 256 * (PS * sl + q)) * 4), z);
           return;
         }
         if constexpr (BRAW) {
           // four pieces of 4 k-rows x 64 images: one M0 write, SGPR bases 4 channel planes apart (minus the 1 KB the immediate offset adds)
           const char* const base = rawsrc + (size_t)cb * cb_bytes + (size_t)so * 4;   // wave-uniform: k-row 0 of the slot
           const size_t d4 = 4 * ch_bytes - 1024;
-          lds_dma4((unsigned)lane_off_raw, base, base + d4, base + 2 * d4, base + 3 * d4, (unsigned)(size_t)(lds_ptr_t)ld);
+          lds_dma4((unsigned)lane_off_raw, base, base + d4, base + 2 * d4, base + 3 * d4, lds_addr(ld));
         } else {
           const char* const base = planes + (size_t)cb * cb_bytes + (size_t)so * 6144;   // wave-uniform
-          const unsigned l0 = (unsigned)(size_t)(lds_ptr_t)ld;
+          const unsigned l0 = lds_addr(ld);
           lds_dma4(lane_off, base, base, base, base, l0);
           lds_dma2(lane_off, base + 4096, base + 4096, l0 + 4096u);
         }
@@ -771,7 +769,6 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
   const int nchunks = 3 * (sc_end - sc_beg);
   const int cb_beg = nrow > 0 ? sgpr(sc_beg / nrow) : 0, r_beg = nrow > 0 ? sgpr(sc_beg % nrow) : 0;   // first superchunk: channel block, tap row - a_lo
 
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
   f32x16 acc[MT][NTC];
 #pragma unroll
   for (int t = 0; t < MT; ++t)
@@ -790,8 +787,8 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
     const unsigned a_lane = (unsigned)lane * 16u;
     const char* const abase0 = reinterpret_cast<const char*>(T.A) + (size_t)row_tile * (6 * ROWS * 16) + 3072u * wave;
     const size_t a_chunk_bytes = (size_t)p.row_tiles * (6 * ROWS * 16);
-    const unsigned lds_a = (unsigned)(size_t)(lds_ptr_t)As + 3072u * wave;
-    const unsigned lds_b = (unsigned)(size_t)(lds_ptr_t)Bs;
+    const unsigned lds_a = lds_addr(As) + 3072u * wave;
+    const unsigned lds_b = lds_addr(Bs);
     const unsigned lds_dump = lds_b + 2u * SLAB * 4u;
     const int gb = p.gb0[0], dstep = dir * p.ssx;   // tap of tap slot i: gb + i*dstep
 
@@ -1025,7 +1022,7 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
         mac_step(K5{}, fa, fc, u);
       }
       // the last column's split is complete HERE (the compiler otherwise sinks it towards its use, out of the MFMA shadow)
-      asm volatile("" ::"v"(fb[(NTC - 1) & 1].h), "v"(fb[(NTC - 1) & 1].m), "v"(fb[(NTC - 1) & 1].l));
+      CHIP_PIN_SPLIT8(fb[(NTC - 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(0x0077);   // vmcnt(7) lgkmcnt(0): everything this wave issued before this chunk's batch has landed
       __syncthreads();                      // ... and every other wave's; every wave has read this chunk's A and slab slots out of LDS
@@ -1044,7 +1041,7 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
         mac_step(K4{}, fa, fc, NTC - 1);
         split_pair(0, 3, fn);
         mac_step(K5{}, fa, fc, NTC - 1);
-        asm volatile("" ::"v"(fn.h), "v"(fn.m), "v"(fn.l));   // (as above: complete here)
+        CHIP_PIN_SPLIT8(fn);   // (as above: complete here)
         __builtin_amdgcn_sched_barrier(0);
       }
     };

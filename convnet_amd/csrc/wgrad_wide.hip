@@ -88,8 +88,6 @@ __global__ __launch_bounds__(256, 1) void wgw_kernel(const WGParams p) {
       for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
 
   if (cend > cbeg) {
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
     // ---- the (pixel, image chunk) walk of the staging, one chunk ahead: wave-uniform, integer arithmetic only ---------------------
     int w_m = sgpr(cbeg / p.nchunk);
     int w_nc = sgpr(cbeg - w_m * p.nchunk);

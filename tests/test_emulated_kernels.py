@@ -1,0 +1,44 @@
+"""gpw_kernel and wgw_kernel — written after the last hardware run of their round — executed FUNCTIONALLY on the CPU: the real kernel
+sources (convnet_amd/csrc/patch_gemm.hip, wgrad_wide.hip) compiled as host C++ against tests/emu/hip/hip_runtime.h (every thread of a
+block a fiber; wave collectives, the bf16 MFMA in the register layout the kernels assume, LDS-DMA as an immediate copy) and run through
+their own host launchers on small convolutions against a double-precision reference (tests/emu/emu_main.cc).  The harness is calibrated
+in the same run on gpp_kernel, which is green on hardware.  No GPU; not a product path.  What this cannot see: timing, late-landing loads
+(tests/test_patch_wide_cpu.py / test_wgrad_wide_cpu.py model those), the M0 range above 84 KB, instruction hazards.
+CONVNET_EMU_ALL=1 runs every case (~2 minutes) instead of one or two per kernel (~1 minute)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _clang():
+    for c in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++")):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+@pytest.fixture(scope="module")
+def emu_binary(tmp_path_factory):
+    cc = _clang()
+    if not cc:
+        pytest.skip("no clang++ (the kernels use clang's vector extensions and __bf16)")
+    exe = tmp_path_factory.mktemp("emu") / "emu_main"
+    subprocess.run([cc, "-std=c++17", "-O1", "-x", "c++", "-I", os.path.join(HERE, "emu"), "-I", os.path.join(ROOT, "convnet_amd", "csrc"), "-Wno-everything",
+                    os.path.join(HERE, "emu", "emu_main.cc"), "-o", str(exe)], check=True)
+    return str(exe)
+
+
+def test_wide_kernels_run_correctly_in_emulation(emu_binary):
+    which = "all" if os.environ.get("CONVNET_EMU_ALL") else "quick"
+    r = subprocess.run([emu_binary, which], capture_output=True, text=True, timeout=1200)
+    lines = r.stdout.strip().splitlines()
+    print(r.stdout)
+    assert r.returncode == 0 and lines and lines[-1] == "ALL PASSED", r.stdout + r.stderr
+    # the calibration case and both kernels really ran
+    assert any(l.startswith("PASS gpp(raw)") for l in lines) and any(l.startswith("PASS gpw fprop") for l in lines)
+    assert any(l.startswith("PASS gpw dgrad") for l in lines) and any(l.startswith("PASS wgw wgrad") for l in lines)
