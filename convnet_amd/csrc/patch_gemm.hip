@@ -660,7 +660,8 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 2) void gpp_kernel(const GGParams
 // the image is a load of the zero page and a slot nobody reads a load into a dump region — every wave issues exactly 7 loads per
 // chunk and waits with a constant count in front of the chunk barrier.
 // Row tiles of 128 are exact for 384 and 256 rows; conv3/4 at 256 images are 254 tiles for 256 CUs.
-// NOT YET RUN ON HARDWARE (written at the end of round 4 with the GPU budget spent): opt-in only, patch mode 3.
+// NOT YET RUN ON HARDWARE (written at the end of round 4 with the GPU budget spent): opt-in only, patch mode 3.  Runs correctly in the
+// CPU emulation of this source (tests/test_emulated_kernels.py); its schedule against late-landing loads: tests/test_patch_wide_cpu.py.
 __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const GGClassTable ct) {
   constexpr int WC = 4, MT = 4, CW = 128, NTC = CW / 32, P = kWideP, NS = kWideNS;
   using fvec = __attribute__((ext_vector_type(NTC))) float;

@@ -15,7 +15,8 @@
 // test, as in wg_kernel) in the first half of the chunk, the split of the next filter column, the split of the second half's four
 // row tiles, and — behind the chunk barrier, which sits two steps before the end — the split of the NEXT chunk's first half, so that no
 // wave reads the current buffers after the barrier and the next chunk may overwrite them at once.  Two LDS stages of 64 KB.
-// NOT YET RUN ON HARDWARE (written at the end of round 4 with the GPU budget spent): opt-in, convnet_hip_set_wgrad_tile(1).
+// NOT YET RUN ON HARDWARE (written at the end of round 4 with the GPU budget spent): opt-in, convnet_hip_set_wgrad_tile(1).  Runs
+// correctly in the CPU emulation of this source (tests/test_emulated_kernels.py); the schedule: tests/test_wgrad_wide_cpu.py.
 #include <algorithm>
 #include <string>
 

@@ -115,14 +115,15 @@ int convnet_hip_get_matrix_path(void);
  *   2: gpp_kernel, planes — the same tile reading the source from bf16 planes written by one extra pass (act_planes_kernel);
  *   3: gpw_kernel — 8 neighbouring pixels x 64 images x 128 rows per block, raw fp32 source, the block's four waves stage for
  *      themselves (3x3 stride-1 gathers with output rows >= 8 pixels; other shapes fall back to mode 0).  EXPERIMENTAL: written after
- *      the last hardware run of its round, checked on the CPU only (tests/test_patch_wide_cpu.py).
+ *      the last hardware run of its round; runs correctly in a CPU emulation of its source (tests/test_emulated_kernels.py).
  * Initial value: environment CONVNET_GG_PATCH, else 0. */
 void convnet_hip_set_patch_mode(int mode);
 int convnet_hip_get_patch_mode(void);
 /* Which kernel runs the weight gradients (conv wgrad, FC wgrad) on matrix path 1 — a schedule choice like the one above:
  *   0: wg_kernel — 128 x 128 tile, four waves of 64 x 64, two blocks per CU;
  *   1: wgw_kernel — 256 x 256 (or 256 x 192) tile, four waves of 128 x 128, one block per CU (N % 32 == 0, K >= 256, F >= 192; other
- *      shapes stay on wg_kernel).  EXPERIMENTAL: written after the last hardware run of its round; its schedule is checked at compile time.
+ *      shapes stay on wg_kernel).  EXPERIMENTAL: written after the last hardware run of its round; runs correctly in a CPU emulation of its
+ *      source (tests/test_emulated_kernels.py), its schedule is checked at compile time.
  * Initial value: environment CONVNET_WG_TILE, else 0. */
 void convnet_hip_set_wgrad_tile(int mode);
 int convnet_hip_get_wgrad_tile(void);
