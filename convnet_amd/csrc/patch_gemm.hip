@@ -1129,6 +1129,9 @@ int patch_slots(Kern kern, int threads, size_t lds) {
   CHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int n = 0;
   CHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), threads, lds));
+#ifdef CONVNET_EMU
+  if (const char* e = getenv("CONVNET_EMU_SLOTS")) return atoi(e);   // tests/emu: a small "chip", so that small problems reach the tail split
+#endif
   return (n < 1 ? 1 : n) * 256;
 }
 
@@ -1243,6 +1246,9 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
         best_s = s;
       }
     }
+#ifdef CONVNET_EMU
+    if (const char* e = getenv("CONVNET_EMU_TAIL")) best_s = atoi(e);   // tests/emu: the cost model never picks it at emulation sizes
+#endif
     if (best_s > 1) {
       p.tail_first = full;
       p.tail_cps = divup(nsc, best_s);

@@ -121,7 +121,8 @@ static void fprop_case(const Geo& g, int mode, const char* tag) {
     patch_run(p, (size_t)g.N * p.DP * g.F, "conv_fprop", 0.0, bank);
   }
   verdict(std::string(tag) + " fprop N" + std::to_string(g.N) + " C" + std::to_string(g.C) + " " + std::to_string(g.H) + "x" + std::to_string(g.W) + " F" +
-              std::to_string(g.F) + " k" + std::to_string(g.Ky) + " p" + std::to_string(g.pad),
+              std::to_string(g.F) + " k" + std::to_string(g.Ky) + " p" + std::to_string(g.pad) + " splits=" + std::to_string(p.splits) + " tail_splits=" +
+              std::to_string(p.tail_splits),
           ok ? rel_err(y, ref) : 1.0, ok);
 }
 
@@ -210,7 +211,7 @@ static void wgrad_case(const Geo& g, bool with_bias, float scaleTargets, float s
 
 int main(int argc, char** argv) {
   const std::string what = argc > 1 ? argv[1] : "quick";   // gpp | gpw | wgw | quick (a subset of each, ~1 minute) | all
-  const bool all = what == "all", quick = what == "quick";
+  const bool all = what == "all", quick = what == "quick";   // ("all" does not include gpwtail: its 8-slot chip is a process-wide setting)
   if (what == "gpp" || all || quick) {   // calibration of the harness on a kernel that is green on hardware
     fprop_case(Geo{64, 16, 9, 9, 96, 3, 3, 1, 1, 1}, 1, "gpp(raw)");
     if (!quick) dgrad_case(Geo{64, 96, 6, 6, 16, 3, 3, 1, 1, 1}, 1, "gpp(raw)");
@@ -221,6 +222,11 @@ int main(int argc, char** argv) {
     if (!quick) fprop_case(Geo{64, 16, 10, 10, 72, 3, 3, 1, 1, 0}, 3, "gpw");   // pad 0: 8-wide output rows
     dgrad_case(Geo{64, 96, 9, 9, 16, 3, 3, 1, 1, 1}, 3, "gpw");
     if (!quick) dgrad_case(Geo{64, 72, 10, 10, 32, 3, 3, 1, 1, 0}, 3, "gpw");   // conv5 type: 8 x 8 derivatives into 10 x 10
+  }
+  if (what == "gpwtail") {   // 11 tiles on an 8-slot "chip", the last round's 3 tiles cut in 3 K-ranges: tail split + gpw_tail_fix_kernel
+    setenv("CONVNET_EMU_SLOTS", "8", 1);   // (read once, at the first patch_run of the mode: run this leg in its own process)
+    setenv("CONVNET_EMU_TAIL", "3", 1);
+    fprop_case(Geo{64, 64, 9, 9, 96, 3, 3, 1, 1, 1}, 3, "gpw(tail split)");
   }
   if (what == "wgw" || all || quick) {
     wgrad_case(Geo{32, 32, 9, 9, 192, 3, 3, 1, 1, 1}, false, 0.f, 1.f);    // 256 x 192 tile, two k tiles (288 rows), border taps

@@ -42,3 +42,11 @@ def test_wide_kernels_run_correctly_in_emulation(emu_binary):
     # the calibration case and both kernels really ran
     assert any(l.startswith("PASS gpp(raw)") for l in lines) and any(l.startswith("PASS gpw fprop") for l in lines)
     assert any(l.startswith("PASS gpw dgrad") for l in lines) and any(l.startswith("PASS wgw wgrad") for l in lines)
+
+
+def test_wide_patch_kernel_tail_split_in_emulation(emu_binary):
+    """11 tiles on an 8-slot "chip": the last round's three tiles are cut into three K-ranges (the kernel's tail-split branch, its raw
+    partial tiles, gpw_tail_fix_kernel) — forced by the harness, the cost model never picks it at emulation sizes"""
+    r = subprocess.run([emu_binary, "gpwtail"], capture_output=True, text=True, timeout=1200)
+    lines = r.stdout.strip().splitlines()
+    assert r.returncode == 0 and lines[-1] == "ALL PASSED" and "tail_splits=3" in lines[0], r.stdout + r.stderr
