@@ -255,7 +255,10 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT]
   int m, n;
   if (p.patch) {
     // unit tile: wave-column wc holds CW/64 units, lane li the images NTC*li % 64 .. + NTC - 1 of unit (NTC*li)/64 of them
-    const int U = col_tile * (WC * (CW / 64)) + wc * (CW / 64) + (NTC * li) / 64;   // WC * CW / 64 units per tile (kPatchP, kWideP)
+    // units per tile: kPatchP (gpp_kernel), kWideP for gpw_kernel's <1, 4, 4, 128> — spelled so that every other instantiation keeps the
+    // constant (and the machine code) it was validated with
+    constexpr int PU = (WR == 1 && WC == 4 && MT == 4 && CW == 128) ? kWideP : kPatchP;
+    const int U = col_tile * PU + wc * (CW / 64) + (NTC * li) / 64;
     const int ib = U / pG;
     if (ib >= p.IB) return;
     m = U - ib * pG;
