@@ -1921,7 +1921,7 @@ void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* tar
       t_flops = 2.0 * g.N * p.G * (double)g.F * p.K;
       const PatchBank bank{filters->data_device, g.F, g.C, g.Ky, g.Kx, 0, 0, 1, 1, g.Ky, g.Kx, false};
       patch_run(p, (size_t)g.N * p.DP * g.F, t_op, t_flops, bank);
-      note_kernel(convnet_hip_get_patch_mode() == 3 ? "gpw_kernel(fprop)" : "gpp_kernel(fprop)", t_flops, p.row_tiles * p.col_tiles, p.splits);
+      note_kernel(convnet_hip_get_patch_mode() >= 3 ? "gpw_kernel(fprop)" : "gpp_kernel(fprop)", t_flops, p.row_tiles * p.col_tiles, p.splits);
       return;
     }
     p.KC = 0;
@@ -2104,7 +2104,7 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
     gg_run_classes(base, ct, vec);
     blocks = ct.c[ct.n - 1].tile_end;
   }
-  note_kernel(!patched ? "gg_kernel(dgrad)" : convnet_hip_get_patch_mode() == 3 ? "gpw_kernel(dgrad)" : "gpp_kernel(dgrad)", alg_flops, blocks, 1);
+  note_kernel(!patched ? "gg_kernel(dgrad)" : convnet_hip_get_patch_mode() >= 3 ? "gpw_kernel(dgrad)" : "gpp_kernel(dgrad)", alg_flops, blocks, 1);
 }
 
 void convDownGemm(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* ds, Shape4D* fs, Shape4D* ts, ConvDesc d,

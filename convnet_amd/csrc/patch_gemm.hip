@@ -662,13 +662,18 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 2) void gpp_kernel(const GGParams
 // Row tiles of 128 are exact for 384 and 256 rows; conv3/4 at 256 images are 254 tiles for 256 CUs.
 // NOT YET RUN ON HARDWARE (written at the end of round 4 with the GPU budget spent): opt-in only, patch mode 3.  Runs correctly in the
 // CPU emulation of this source (tests/test_emulated_kernels.py); its schedule against late-landing loads: tests/test_patch_wide_cpu.py.
+// VAR (patch modes 3 / 4 / 5, for the first A/B on hardware): 0 = one staging load per step, three-stage filter ring; 1 = the loads in
+// groups of three and four back to back; 2 = as 0 with the filter chunk staged ONE ahead into a TWO-stage ring (124 KB of LDS instead of
+// 136: nothing DMA-written above 128 KB, should M0 turn out narrower than the LDS).
+template <int VAR>
 __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const GGClassTable ct) {
   constexpr int WC = 4, MT = 4, CW = 128, NTC = CW / 32, P = kWideP, NS = kWideNS;
   using fvec = __attribute__((ext_vector_type(NTC))) float;
   constexpr int NC = WC * 64;
   constexpr int ROWS = MT * 32;
   constexpr int A_STAGE = 6 * ROWS * 4;   // floats: 3 planes x 2 k-groups x ROWS x 16 bytes
-  constexpr int STA = 3;                  // A ring
+  constexpr bool GROUPED = VAR == 1;
+  constexpr int STA = VAR == 2 ? 2 : 3;   // A ring
   constexpr int SLAB = NS * 1024;         // floats per slab: a slot is 16 k-rows x 64 images of fp32
   static_assert(A_STAGE * 4 == WC * 3 * 1024, "three 1 KB pieces of a filter chunk per wave");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -804,7 +809,7 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
     const char* a_ptr = abase0 + a_chunk_bytes * (size_t)(cb_beg * TYX + (a_lo + r_beg) * TX + gb);   // wave-uniform
     // counters as plain integer arithmetic (0/1 flags, masks): booleans with && / ?: come back from the optimizer as branches
     int A_i = 0, A_r = r_beg, A_left = nchunks;   // tap slot, tap row - a_lo, chunks not yet issued
-    unsigned lds_f0 = lds_a, lds_f1 = lds_a + A_STAGE * 4u, lds_f2 = lds_a + 2u * A_STAGE * 4u;   // the ring stage to fill next first
+    unsigned lds_f0 = lds_a, lds_f1 = lds_a + A_STAGE * 4u, lds_f2 = lds_a + 2u * A_STAGE * 4u;   // the ring stage to fill next first (STA == 2: f2 unused)
     // (in two parts, so that a chunk can place them in different steps: the address into SGPRs, then the loads and the stepping)
     const char* a_cur = nullptr;
     unsigned a_lds = 0;
@@ -817,8 +822,12 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
     auto issue_a_step = [&]() __attribute__((always_inline)) {
       const unsigned f = lds_f0;
       lds_f0 = lds_f1;
-      lds_f1 = lds_f2;
-      lds_f2 = f;
+      if constexpr (STA == 3) {
+        lds_f1 = lds_f2;
+        lds_f2 = f;
+      } else {
+        lds_f1 = f;
+      }
       --A_left;
       const int more = (int)((unsigned)(-A_left) >> 31);   // 1 while chunks are left
       const int i1 = A_i + 1, w1 = (i1 * 11) >> 5;          // w1 = 1 when the tap row is complete (i1 == 3)
@@ -930,7 +939,7 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
       bufsel ^= (unsigned)w;
       sc += w;
       slab_next(w);
-      const int s1 = stage + 1, ws = (s1 * 11) >> 5;
+      const int s1 = stage + 1, ws = 1 - (int)((unsigned)(s1 - STA) >> 31);   // ws = 1: wrap
       stage = s1 - STA * ws;
     };
 
@@ -942,7 +951,7 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
       slab_next(1);
     }
     issue_a();
-    issue_a();
+    if constexpr (STA == 3) issue_a();   // (two ahead; the two-stage ring runs one ahead)
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
     __syncthreads();
 
@@ -1001,19 +1010,19 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
         // 0: which load the slot is, its addresses; column 1: the filter iterator) and the counters of the NEXT chunk (column 2).
         split_pair(u + 1, 0, fn);
         if (u == 0) issue_a_addr();
-        if (u == 1) slot_piece(K0{});
+        if (u == 1) { if constexpr (GROUPED) slot_go(); else slot_piece(K0{}); }
         mac_step(K0{}, fa, fc, u);
         split_pair(u + 1, 1, fn);
-        if (u == 0) issue_a_piece(K0{});
-        if (u == 1) slot_piece(K1{});
+        if (u == 0) { if constexpr (GROUPED) issue_a_go(); else issue_a_piece(K0{}); }
+        if (u == 1 && !GROUPED) slot_piece(K1{});
         mac_step(K1{}, fa, fc, u);
         split_pair(u + 1, 2, fn);
-        if (u == 0) issue_a_piece(K1{});
-        if (u == 1) slot_piece(K2{});
+        if (u == 0 && !GROUPED) issue_a_piece(K1{});
+        if (u == 1 && !GROUPED) slot_piece(K2{});
         mac_step(K2{}, fa, fc, u);
         split_pair(u + 1, 3, fn);
-        if (u == 0) issue_a_piece(K2{});
-        if (u == 1) slot_piece(K3{});
+        if (u == 0 && !GROUPED) issue_a_piece(K2{});
+        if (u == 1 && !GROUPED) slot_piece(K3{});
         mac_step(K3{}, fa, fc, u);
         if (u == 0) next_slot_kind();
         if (u == 1) issue_a_step();
@@ -1025,7 +1034,9 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
       // the last column's split is complete HERE (the compiler otherwise sinks it towards its use, out of the MFMA shadow)
       CHIP_PIN_SPLIT8(fb[(NTC - 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0x0077);   // vmcnt(7) lgkmcnt(0): everything this wave issued before this chunk's batch has landed
+      // everything this wave issued before this chunk's batch has landed: vmcnt(7) lgkmcnt(0) — with the two-stage ring this chunk's three
+      // filter loads too (they are the first of the seven): vmcnt(4)
+      __builtin_amdgcn_s_waitcnt(STA == 3 ? 0x0077 : 0x0074);
       __syncthreads();                      // ... and every other wave's; every wave has read this chunk's A and slab slots out of LDS
       {
         const Split8& fc = fb[(NTC - 1) & 1];
@@ -1154,7 +1165,7 @@ bool patch_shape_ok(GGParams& p) {
   }
   if (p.ng == 1) { p.gcnt[1] = p.gcnt[0]; p.gb0[1] = p.gb0[0]; }
   // gpw_kernel: 3-tap rows of a stride-1 gather; its 12 slots hold ONE wrap per tile: output rows of >= 8 pixels
-  if (patch_mode() == 3 && (p.ng != 1 || p.gcnt[0] != 3 || p.GX < kWideP)) return false;
+  if (patch_mode() >= 3 && (p.ng != 1 || p.gcnt[0] != 3 || p.GX < kWideP)) return false;
   return true;
 }
 
@@ -1165,9 +1176,9 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
   constexpr int ROWS = 128;                         // both kernels
   static_assert(ROWS == WR * MT * 32, "row tile");
   // CONVNET_GG_PATCH / convnet_hip_set_patch_mode: 1 = gpp_kernel on a raw fp32 slab, split by the consumers; 2 = gpp_kernel on bf16
-  // planes of the source tensor (one more pass); 3 = gpw_kernel (8 units x 128 rows, raw slab, no producer wave)
+  // planes of the source tensor (one more pass); 3 / 4 / 5 = gpw_kernel (8 units x 128 rows, raw slab, no producer wave) and its two variants
   const int mode = patch_mode();
-  const bool wide = mode == 3, braw = mode != 2;
+  const bool wide = mode >= 3, braw = mode != 2;
   const int PU = wide ? kWideP : kPatchP;           // units per tile
   const int TCOLS = PU * 64;                        // columns per tile
   const int threads = wide ? 256 : WR * WC * 64 + 64;
@@ -1201,10 +1212,13 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
   p.zero = zero_page();
   p.prio = CHIP_DIAG_KNOB("CONVNET_GPP_DIAG", 0);
   constexpr size_t lds_p = sizeof(float) * (3 * (6 * ROWS * 4) + 2 * (6 * 8 * 256)), lds_r = sizeof(float) * (3 * (6 * ROWS * 4) + 2 * (4 * 8 * 256));
-  constexpr size_t lds_w = sizeof(float) * (3 * (6 * ROWS * 4) + 2 * (kWideNS * 1024) + 1024);   // + the dump slot
+  constexpr size_t lds_w3 = sizeof(float) * (3 * (6 * ROWS * 4) + 2 * (kWideNS * 1024) + 1024);   // + the dump slot
+  constexpr size_t lds_w2 = lds_w3 - sizeof(float) * (6 * ROWS * 4);                               // two-stage filter ring (mode 5)
+  const size_t lds_w = mode == 5 ? lds_w2 : lds_w3;
   static const int slots_p = patch_slots(gpp_kernel<WR, WC, MT, CW, false>, WR * WC * 64 + 64, lds_p);
   static const int slots_r = patch_slots(gpp_kernel<WR, WC, MT, CW, true>, WR * WC * 64 + 64, lds_r);
-  static const int slots_w = patch_slots(gpw_kernel, 256, lds_w);
+  static const int slots_w0 = patch_slots(gpw_kernel<0>, 256, lds_w3), slots_w1 = patch_slots(gpw_kernel<1>, 256, lds_w3), slots_w2 = patch_slots(gpw_kernel<2>, 256, lds_w2);
+  const int slots_w = mode == 5 ? slots_w2 : mode == 4 ? slots_w1 : slots_w0;
   const int slots = wide ? slots_w : braw ? slots_r : slots_p;
   const int tiles = p.row_tiles * p.col_tiles;
   const int TYn = p.TYX / p.TX;
@@ -1262,8 +1276,10 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
   static const GGClassTable kNone = {};
   {
     // (",split" in a timer name is how bench.py prices the kernel on the bf16 pipe: kernel_peak)
-    KernelTimer timer(wide ? "gpw_kernel<128x512,split,raw>" : braw ? "gpp_kernel<2,2,2,128,split,raw>" : "gpp_kernel<2,2,2,128,split,planes>", op, flops, 0.0, 0.0);
-    if (wide) hipLaunchKernelGGL(gpw_kernel, grid, dim3(threads), lds_w, stream(), p, kNone);
+    KernelTimer timer(mode == 5 ? "gpw_kernel<128x512,split,raw,ring2>" : mode == 4 ? "gpw_kernel<128x512,split,raw,grouped>" : wide ? "gpw_kernel<128x512,split,raw>" : braw ? "gpp_kernel<2,2,2,128,split,raw>" : "gpp_kernel<2,2,2,128,split,planes>", op, flops, 0.0, 0.0);
+    if (mode == 5) hipLaunchKernelGGL(gpw_kernel<2>, grid, dim3(threads), lds_w, stream(), p, kNone);
+    else if (mode == 4) hipLaunchKernelGGL(gpw_kernel<1>, grid, dim3(threads), lds_w, stream(), p, kNone);
+    else if (wide) hipLaunchKernelGGL(gpw_kernel<0>, grid, dim3(threads), lds_w, stream(), p, kNone);
     else if (braw) hipLaunchKernelGGL((gpp_kernel<WR, WC, MT, CW, true>), grid, dim3(threads), lds_r, stream(), p, kNone);
     else hipLaunchKernelGGL((gpp_kernel<WR, WC, MT, CW, false>), grid, dim3(threads), lds_p, stream(), p, kNone);
   }
@@ -1279,6 +1295,6 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
 }  // namespace chip
 
 extern "C" {
-void convnet_hip_set_patch_mode(int mode) { chip::g_patch_mode = mode < 0 ? 0 : mode > 3 ? 3 : mode; }
+void convnet_hip_set_patch_mode(int mode) { chip::g_patch_mode = mode < 0 ? 0 : mode > 5 ? 5 : mode; }
 int convnet_hip_get_patch_mode(void) { return chip::patch_mode(); }
 }

@@ -116,6 +116,8 @@ int convnet_hip_get_matrix_path(void);
  *   3: gpw_kernel — 8 neighbouring pixels x 64 images x 128 rows per block, raw fp32 source, the block's four waves stage for
  *      themselves (3x3 stride-1 gathers with output rows >= 8 pixels; other shapes fall back to mode 0).  EXPERIMENTAL: written after
  *      the last hardware run of its round; runs correctly in a CPU emulation of its source (tests/test_emulated_kernels.py).
+ *   4, 5: variants of 3 for the first A/B on hardware (4: its staging loads in groups instead of one per step; 5: a two-stage filter
+ *      ring, 124 KB of LDS).
  * Initial value: environment CONVNET_GG_PATCH, else 0. */
 void convnet_hip_set_patch_mode(int mode);
 int convnet_hip_get_patch_mode(void);

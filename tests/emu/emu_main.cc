@@ -223,6 +223,13 @@ int main(int argc, char** argv) {
     dgrad_case(Geo{64, 96, 9, 9, 16, 3, 3, 1, 1, 1}, 3, "gpw");
     if (!quick) dgrad_case(Geo{64, 72, 10, 10, 32, 3, 3, 1, 1, 0}, 3, "gpw");   // conv5 type: 8 x 8 derivatives into 10 x 10
   }
+  if (what == "gpwvar" || all) {   // its two variants: grouped staging loads (mode 4), two-stage filter ring (mode 5)
+    fprop_case(Geo{64, 16, 9, 9, 96, 3, 3, 1, 1, 1}, 4, "gpw(grouped)");
+    dgrad_case(Geo{64, 96, 9, 9, 16, 3, 3, 1, 1, 1}, 4, "gpw(grouped)");
+    fprop_case(Geo{64, 16, 9, 9, 96, 3, 3, 1, 1, 1}, 5, "gpw(ring2)");
+    fprop_case(Geo{128, 32, 8, 8, 130, 3, 3, 1, 1, 1}, 5, "gpw(ring2)");
+    dgrad_case(Geo{64, 96, 9, 9, 16, 3, 3, 1, 1, 1}, 5, "gpw(ring2)");
+  }
   if (what == "gpwtail") {   // 11 tiles on an 8-slot "chip", the last round's 3 tiles cut in 3 K-ranges: tail split + gpw_tail_fix_kernel
     setenv("CONVNET_EMU_SLOTS", "8", 1);   // (read once, at the first patch_run of the mode: run this leg in its own process)
     setenv("CONVNET_EMU_TAIL", "3", 1);

@@ -150,10 +150,11 @@ WIDE_DGRAD = [
 ]
 
 
-@pytest.fixture
-def wide_mode(hip):
+@pytest.fixture(params=[3, 4, 5], ids=["gpw", "gpw_grouped", "gpw_ring2"])
+def wide_mode(request, hip):
+    """gpw_kernel and its two variants (include/convnet_hip.h: patch modes 3 / 4 / 5)"""
     from convnet_amd import _lib
-    _lib.lib.convnet_hip_set_patch_mode(3)
+    _lib.lib.convnet_hip_set_patch_mode(request.param)
     yield
     _lib.lib.convnet_hip_set_patch_mode(1)
 

@@ -17,9 +17,10 @@ P, NS, WAVES = 8, 12, 4
 NO_SLOT, ZERO_SLOT = -1, -2
 
 
-def run_tile(par, src, bank, col_tile, lazy):
+def run_tile(par, src, bank, col_tile, lazy, sta=3):
     """One block of gpw_kernel.  par: the GGParams fields the kernel reads; src [KC][SH][SW][N]; bank[q] = filter chunk q as a
-    [R][16] matrix (chunk q = cb*TYX + a*TX + b).  Returns {unit j: [R][64] accumulator}."""
+    [R][16] matrix (chunk q = cb*TYX + a*TX + b).  sta: stages of the filter ring (3: filter chunk two ahead, wait vmcnt(7); 2: one
+    ahead, the chunk's own filter loads are the first of its seven and the wait is vmcnt(4)).  Returns {unit j: [R][64] accumulator}."""
     G, GX, IB, N = par["G"], par["GX"], par["IB"], par["N"]
     SH, SW, ssy, ssx, y0, x0, d = par["SH"], par["SW"], par["ssy"], par["ssx"], par["y0"], par["x0"], par["dir"]
     TX, TYX, gb = par["TX"], par["TYX"], par["gb0"]
@@ -71,30 +72,30 @@ def run_tile(par, src, bank, col_tile, lazy):
     if nchunks == 0:
         return acc
     # ---- LDS and in-flight loads
-    A_lds = [np.full((R, 16), np.nan) for _ in range(3)]
+    A_lds = [np.full((R, 16), np.nan) for _ in range(sta)]
     B_lds = [[np.full((16, 64), np.nan) for _ in range(NS)] for _ in range(2)]
     inflight = [[] for _ in range(WAVES)]   # per wave: (landing closure, batch id)
 
-    def issue(w, fn, batch_id):
+    def issue(w, fn, batch_id, is_filter=False):
         if lazy:
-            inflight[w].append((fn, batch_id))
+            inflight[w].append((fn, batch_id, is_filter))
         else:
             fn()
 
-    def wait_all_but_batch(w, batch_id):   # vmcnt(7): everything issued before this chunk's batch has landed
+    def wait_all_but_batch(w, batch_id):   # vmcnt(7): everything issued before this chunk's batch; vmcnt(4): and its three filter loads
         keep = []
-        for fn, b in inflight[w]:
-            if b < batch_id:
+        for fn, b, is_filter in inflight[w]:
+            if b < batch_id or (sta == 2 and b == batch_id and is_filter):
                 fn()
             else:
-                keep.append((fn, b))
+                keep.append((fn, b, is_filter))
         inflight[w] = keep
 
     dstep = d * ssx
     a_tap, a_row_x, a_cbs_x = dstep, TX - 3 * dstep, TYX - (a_hi - a_lo + 1) * TX
     # every wave carries the same iterators; one copy here, the loads tagged with the wave that issues them
     st = dict(a_q=(sc_beg // nrow) * TYX + (a_lo + sc_beg % nrow) * TX + gb, A_i=0, A_r=sc_beg % nrow, A_left=nchunks,
-              f=[0, 1, 2], B_r=sc_beg % nrow, B_cb=sc_beg // nrow)
+              f=list(range(sta)), B_r=sc_beg % nrow, B_cb=sc_beg // nrow)
 
     def issue_a(batch_id):
         q, stage = st["a_q"], st["f"][0]
@@ -104,7 +105,7 @@ def run_tile(par, src, bank, col_tile, lazy):
 
             def land(rows=rows, q=q, stage=stage):
                 A_lds[stage][rows] = bank[q][rows]
-            issue(w, land, batch_id)
+            issue(w, land, batch_id, True)
         st["f"] = st["f"][1:] + st["f"][:1]
         st["A_left"] -= 1
         more = 1 if st["A_left"] > 0 else 0
@@ -142,7 +143,8 @@ def run_tile(par, src, bank, col_tile, lazy):
             issue_slot(w, my_ord[w][q], 0, st["B_cb"], desc0, True, -3)
     slab_next(1)
     issue_a(-2)
-    issue_a(-2)
+    if sta == 3:
+        issue_a(-2)
     for w in range(WAVES):
         wait_all_but_batch(w, 10 ** 9)
     # consumer state
@@ -172,14 +174,14 @@ def run_tile(par, src, bank, col_tile, lazy):
         bufsel ^= wv
         sc += wv
         slab_next(wv)
-        stage = (stage + 1) % 3
+        stage = (stage + 1) % sta
         for w in range(WAVES):
             wait_all_but_batch(w, c)
         cur = read_chunk() if c + 1 < nchunks else None
     return acc
 
 
-def conv_by_tiles(g, x, w, dgrad, lazy):
+def conv_by_tiles(g, x, w, dgrad, lazy, sta=3):
     """fprop of g (or the input gradient of a stride-1 g) assembled from gpw_kernel tiles; x / w in the oracle's layouts."""
     if not dgrad:
         C, F = g.C, g.F
@@ -199,7 +201,7 @@ def conv_by_tiles(g, x, w, dgrad, lazy):
         GXo = g.W
     units = par["IB"] * par["G"]
     for ct in range((units + P - 1) // P):
-        acc = run_tile(par, x, bank, ct, lazy)
+        acc = run_tile(par, x, bank, ct, lazy, sta)
         for j, v in acc.items():
             U = ct * P + j
             ib, m = divmod(U, par["G"])
@@ -223,25 +225,27 @@ DGRAD = [
 _id = lambda g: f"N{g.N}C{g.C}H{g.H}W{g.W}F{g.F}k{g.Ky}x{g.Kx}p{g.pady}"  # noqa: E731
 
 
+@pytest.mark.parametrize("sta", [3, 2], ids=["ring3", "ring2"])
 @pytest.mark.parametrize("lazy", [False, True], ids=["eager", "lazy"])
 @pytest.mark.parametrize("g", FPROP, ids=_id)
-def test_wide_tile_schedule_fprop(g, lazy):
+def test_wide_tile_schedule_fprop(g, lazy, sta):
     rng = np.random.default_rng(5)
     x = rng.standard_normal(g.in_shape()).astype(np.float32)
     w = rng.standard_normal(g.filt_shape()).astype(np.float32)
     ref = oracle.port.conv_up(g, x, w).astype(np.float64)
-    got = conv_by_tiles(g, x, w, False, lazy)
+    got = conv_by_tiles(g, x, w, False, lazy, sta)
     assert not np.isnan(got).any()
     assert np.abs(got - ref).max() < 2e-4 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("sta", [3, 2], ids=["ring3", "ring2"])
 @pytest.mark.parametrize("lazy", [False, True], ids=["eager", "lazy"])
 @pytest.mark.parametrize("g", DGRAD, ids=_id)
-def test_wide_tile_schedule_dgrad(g, lazy):
+def test_wide_tile_schedule_dgrad(g, lazy, sta):
     rng = np.random.default_rng(6)
     dy = rng.standard_normal(g.out_shape()).astype(np.float32)
     w = rng.standard_normal(g.filt_shape()).astype(np.float32)
     ref = oracle.port.conv_down(g, dy, w).astype(np.float64)
-    got = conv_by_tiles(g, dy, w, True, lazy)
+    got = conv_by_tiles(g, dy, w, True, lazy, sta)
     assert not np.isnan(got).any()
     assert np.abs(got - ref).max() < 2e-4 * np.abs(ref).max()

@@ -14,7 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from convnet_amd import build as B  # noqa: E402
 
-KERNELS = {"patch_gemm.hip": [("gpw_kernel", "_ZN4chip10gpw_kernelENS_8GGParamsENS_12GGClassTableE", 96)],
+KERNELS = {"patch_gemm.hip": [("gpw_kernel<0> (one staging load per step)", "_ZN4chip10gpw_kernelILi0EEEvNS_8GGParamsENS_12GGClassTableE", 96),
+                              ("gpw_kernel<1> (grouped staging loads)", "_ZN4chip10gpw_kernelILi1EEEvNS_8GGParamsENS_12GGClassTableE", 96),
+                              ("gpw_kernel<2> (two-stage filter ring)", "_ZN4chip10gpw_kernelILi2EEEvNS_8GGParamsENS_12GGClassTableE", 96)],
            "wgrad_wide.hip": [("wgw_kernel<3> (256 x 192)", "_ZN4chip10wgw_kernelILi3EEEvNS_8WGParamsE", 144),
                               ("wgw_kernel<4> (256 x 256)", "_ZN4chip10wgw_kernelILi4EEEvNS_8WGParamsE", 192)]}
 

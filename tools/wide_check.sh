@@ -26,6 +26,13 @@ for rep in 1 2; do
     echo "patch=$1 wgrad_tile=$2 rep=$rep rc=$?"; grep -E "conv[2345]" "$O/layers_p$1_w$2_$rep.log" | head -16
   done
 done
+if [ $GPW = 3 ]; then
+  echo "== gpw_kernel's variants on conv3-5 fprop / dgrad: 3 one load per step, 4 grouped loads, 5 two-stage filter ring =="
+  for v in 3 4 5; do
+    CONVNET_GG_PATCH=$v timeout 120 python tools/layer_bench.py --only conv --reps 5 > "$O/layers_variant_p$v.log" 2>&1
+    echo "patch=$v rc=$?"; grep -E "conv[345]" "$O/layers_variant_p$v.log" | head -12
+  done
+fi
 echo "== the step: default, each new kernel alone, both =="
 for v in "0 0" "$GPW 0" "0 $WGW" "$GPW $WGW"; do
   set -- $v
