@@ -14,7 +14,10 @@ struct Unit {
 };
 constexpr int kMaxUnits = 5;
 
-template <int NTL>
+// FV (fetch variant, for the first A/B on hardware): 0 = the staging loads in the first sub-steps of the chunk, one each (the most time to
+// land, but the first half of the chunk then carries 6 other instructions per MFMA gap); 1 = spread evenly over everything in front of
+// the last step before the barrier.
+template <int NTL, int FV = 0>
 struct Schedule {
   static constexpr int COLS = 2 * NTL, G = 6 * COLS, NSLOT = NTL == 4 ? 4 : 3, GB = 6 * (COLS - 2);   // barrier in front of sub-step GB
   static constexpr int NA = 8, NB = 2 * NTL, NF = NA + NB;
@@ -24,8 +27,12 @@ struct Schedule {
   constexpr Schedule() {
     // staging of the next chunk: one piece per sub-step from the start (they need the rest of the chunk to land)
     add(0, Unit{kWalkBegin, 0, 0, 0});
-    for (int i = 0; i < NF; ++i) add(i, Unit{kFetch, i, 0, 0});
-    add(NF, Unit{kWalkStep, 0, 0, 0});
+    int last = 0;
+    for (int i = 0; i < NF; ++i) {
+      last = FV == 0 ? i : (i * (GB - 6)) / NF;
+      add(last, Unit{kFetch, i, 0, 0});
+    }
+    add(last + 1, Unit{kWalkStep, 0, 0, 0});
     // filter columns: column j + 1 during step j; the last two before the barrier (both in step COLS - 3); the next chunk's column 0 in the last step
     for (int j = 0; j + 3 < COLS; ++j) {
       add(6 * j, Unit{kReadB, j + 1, 0, 0});
@@ -80,9 +87,9 @@ struct Schedule {
 };
 
 // The rules the kernel relies on, checked at compile time.
-template <int NTL>
+template <int NTL, int FV = 0>
 constexpr bool schedule_ok() {
-  using S = Schedule<NTL>;
+  using S = Schedule<NTL, FV>;
   constexpr S s{};
   int readB[S::COLS + 1] = {}, readA[2][4] = {}, pairB[S::COLS + 1][4] = {}, pairA[2][4][4] = {}, fetch[S::NF] = {};
   for (int j = 0; j <= S::COLS; ++j) {
@@ -133,7 +140,7 @@ constexpr bool schedule_ok() {
   }
   if (walk_begin != 0 || walk_step < 0) return false;
   for (int i = 0; i < S::NF; ++i)
-    if (fetch[i] < 0 || fetch[i] >= 6 * NTL) return false;   // staged in the first half: the second half is their time to land
+    if (fetch[i] < 0 || fetch[i] >= (FV == 0 ? 6 * NTL : S::GB - 6)) return false;   // staged early: at least the last step in front of the barrier is their time to land
   for (int j = 1; j <= S::COLS; ++j) {
     for (int q = 0; q < 4; ++q) {
       if (pairB[j][q] < 0) return false;
@@ -153,9 +160,9 @@ constexpr bool schedule_ok() {
     if (readA[1][t] >= S::GB || readA[0][t] < S::GB) return false;
   return true;
 }
-static_assert(schedule_ok<3>() && schedule_ok<4>(), "wgw_kernel: schedule breaks a rule");
-template <int NTL>
-inline constexpr Schedule<NTL> kSchedule{};
+static_assert(schedule_ok<3>() && schedule_ok<4>() && schedule_ok<3, 1>() && schedule_ok<4, 1>(), "wgw_kernel: schedule breaks a rule");
+template <int NTL, int FV>
+inline constexpr Schedule<NTL, FV> kSchedule{};
 
 }  // namespace wgw
 }  // namespace chip

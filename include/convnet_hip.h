@@ -126,6 +126,7 @@ int convnet_hip_get_patch_mode(void);
  *   1: wgw_kernel — 256 x 256 (or 256 x 192) tile, four waves of 128 x 128, one block per CU (N % 32 == 0, K >= 256, F >= 192; other
  *      shapes stay on wg_kernel).  EXPERIMENTAL: written after the last hardware run of its round; runs correctly in a CPU emulation of its
  *      source (tests/test_emulated_kernels.py), its schedule is checked at compile time.
+ *   2: as 1 with the staging loads of a chunk spread over the chunk instead of issued at its start (variant for the first A/B on hardware).
  * Initial value: environment CONVNET_WG_TILE, else 0. */
 void convnet_hip_set_wgrad_tile(int mode);
 int convnet_hip_get_wgrad_tile(void);

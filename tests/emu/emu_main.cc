@@ -167,7 +167,7 @@ static void dgrad_case(const Geo& g, int mode, const char* tag) {
 }
 
 // dW[f + F*k], k = c*TYX + tap; optional bias-gradient row
-static void wgrad_case(const Geo& g, bool with_bias, float scaleTargets, float scaleOutput) {
+static void wgrad_case(const Geo& g, bool with_bias, float scaleTargets, float scaleOutput, int tile_mode = 1) {
   const int My = g.My(), Mx = g.Mx(), TYX = g.Ky * g.Kx, K = g.C * TYX;
   auto xv = rnd((size_t)g.C * g.H * g.W * g.N, 7), dv = rnd((size_t)g.F * My * Mx * g.N, 8), wv = rnd((size_t)g.F * K, 9), bv = rnd(g.F, 10);
   float *x = al16(xv), *dy = al16(dv), *dw = al16(wv), *db = al16(bv);
@@ -191,7 +191,7 @@ static void wgrad_case(const Geo& g, bool with_bias, float scaleTargets, float s
     for (size_t i = 0; i < (size_t)My * Mx * g.N; ++i) sb += dy[(size_t)f * My * Mx * g.N + i];
     refb[f] = scaleTargets * db[f] + scaleOutput * sb;
   }
-  convnet_hip_set_wgrad_tile(1);
+  convnet_hip_set_wgrad_tile(tile_mode);
   WGParams p{};   // conv_outp_impl (gather_gemm.hip)
   p.bias_dst = with_bias ? db : nullptr;
   p.src = x; p.dout = dy; p.dst = dw;
@@ -203,7 +203,7 @@ static void wgrad_case(const Geo& g, bool with_bias, float scaleTargets, float s
   const bool ok = wgw_try(p, true, true, "conv_wgrad", 0.0, 0.0);
   double err = ok ? rel_err(dw, ref) : 1.0;
   if (ok && with_bias && p.bias_dst) err = std::max(err, rel_err(db, refb));
-  verdict("wgw wgrad N" + std::to_string(g.N) + " C" + std::to_string(g.C) + " " + std::to_string(g.H) + "x" + std::to_string(g.W) + " F" + std::to_string(g.F) +
+  verdict(std::string(tile_mode == 2 ? "wgw(spread)" : "wgw") + " wgrad N" + std::to_string(g.N) + " C" + std::to_string(g.C) + " " + std::to_string(g.H) + "x" + std::to_string(g.W) + " F" + std::to_string(g.F) +
               " k" + std::to_string(g.Ky) + " s" + std::to_string(g.sy) + " p" + std::to_string(g.pad) + (with_bias ? (p.bias_dst ? " +bias row" : " (no spare row for the bias)") : "") +
               " splits=" + std::to_string(p.splits),
           err, ok);
@@ -239,6 +239,10 @@ int main(int argc, char** argv) {
     wgrad_case(Geo{32, 32, 9, 9, 192, 3, 3, 1, 1, 1}, false, 0.f, 1.f);    // 256 x 192 tile, two k tiles (288 rows), border taps
     if (!quick) wgrad_case(Geo{64, 29, 8, 8, 200, 3, 3, 1, 1, 1}, true, 1.f, 0.5f);    // 256 x 256 tile ragged in f, K = 261: bias row in the second k tile, two chunks per pixel
     if (!quick) wgrad_case(Geo{64, 16, 12, 12, 224, 5, 5, 2, 2, 2}, false, 0.f, 1.f);  // stride 2, 5 x 5, two chunks per pixel
+  }
+  if (what == "wgwvar" || all) {   // the staging loads spread over the chunk (wgrad tile 2)
+    wgrad_case(Geo{32, 32, 9, 9, 192, 3, 3, 1, 1, 1}, false, 0.f, 1.f, 2);
+    wgrad_case(Geo{64, 29, 8, 8, 200, 3, 3, 1, 1, 1}, true, 1.f, 0.5f, 2);
   }
   std::printf("%s\n", g_fail ? "SOME FAILED" : "ALL PASSED");
   return g_fail ? 1 : 0;

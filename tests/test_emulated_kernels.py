@@ -51,6 +51,13 @@ def test_wide_patch_kernel_variants_in_emulation(emu_binary):
     assert r.returncode == 0 and lines[-1] == "ALL PASSED" and sum(l.startswith("PASS gpw(ring2)") for l in lines) == 3, r.stdout + r.stderr
 
 
+@pytest.mark.skipif(not os.environ.get("CONVNET_EMU_ALL"), reason="the fetch variant of wgw_kernel: CONVNET_EMU_ALL=1 (~25 s)")
+def test_wide_wgrad_kernel_variant_in_emulation(emu_binary):
+    r = subprocess.run([emu_binary, "wgwvar"], capture_output=True, text=True, timeout=1200)
+    lines = r.stdout.strip().splitlines()
+    assert r.returncode == 0 and lines[-1] == "ALL PASSED" and sum(l.startswith("PASS wgw(spread)") for l in lines) == 2, r.stdout + r.stderr
+
+
 def test_wide_patch_kernel_tail_split_in_emulation(emu_binary):
     """11 tiles on an 8-slot "chip": the last round's three tiles are cut into three K-ranges (the kernel's tail-split branch, its raw
     partial tiles, gpw_tail_fix_kernel) — forced by the harness, the cost model never picks it at emulation sizes"""

@@ -34,10 +34,11 @@ def hip():
     return HipImpl()
 
 
-@pytest.fixture
-def wide(hip):
+@pytest.fixture(params=[1, 2], ids=["wgw", "wgw_spread"])
+def wide(request, hip):
+    """wgw_kernel and its fetch variant (include/convnet_hip.h: wgrad tile 1 / 2)"""
     from convnet_amd import _lib
-    _lib.lib.convnet_hip_set_wgrad_tile(1)
+    _lib.lib.convnet_hip_set_wgrad_tile(request.param)
     yield
     _lib.lib.convnet_hip_set_wgrad_tile(0)
 

@@ -17,8 +17,10 @@ from convnet_amd import build as B  # noqa: E402
 KERNELS = {"patch_gemm.hip": [("gpw_kernel<0> (one staging load per step)", "_ZN4chip10gpw_kernelILi0EEEvNS_8GGParamsENS_12GGClassTableE", 96),
                               ("gpw_kernel<1> (grouped staging loads)", "_ZN4chip10gpw_kernelILi1EEEvNS_8GGParamsENS_12GGClassTableE", 96),
                               ("gpw_kernel<2> (two-stage filter ring)", "_ZN4chip10gpw_kernelILi2EEEvNS_8GGParamsENS_12GGClassTableE", 96)],
-           "wgrad_wide.hip": [("wgw_kernel<3> (256 x 192)", "_ZN4chip10wgw_kernelILi3EEEvNS_8WGParamsE", 144),
-                              ("wgw_kernel<4> (256 x 256)", "_ZN4chip10wgw_kernelILi4EEEvNS_8WGParamsE", 192)]}
+           "wgrad_wide.hip": [("wgw_kernel<3, 0> (256 x 192, staging loads first)", "_ZN4chip10wgw_kernelILi3ELi0EEEvNS_8WGParamsE", 144),
+                              ("wgw_kernel<4, 0> (256 x 256, staging loads first)", "_ZN4chip10wgw_kernelILi4ELi0EEEvNS_8WGParamsE", 192),
+                              ("wgw_kernel<3, 1> (256 x 192, staging loads spread)", "_ZN4chip10wgw_kernelILi3ELi1EEEvNS_8WGParamsE", 144),
+                              ("wgw_kernel<4, 1> (256 x 256, staging loads spread)", "_ZN4chip10wgw_kernelILi4ELi1EEEvNS_8WGParamsE", 192)]}
 
 
 def instr(lines):

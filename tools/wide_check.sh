@@ -33,6 +33,13 @@ if [ $GPW = 3 ]; then
     echo "patch=$v rc=$?"; grep -E "conv[345]" "$O/layers_variant_p$v.log" | head -12
   done
 fi
+if [ $WGW = 1 ]; then
+  echo "== wgw_kernel's fetch variant on conv2-5 wgrad: 1 staging loads first, 2 spread over the chunk =="
+  for v in 1 2; do
+    CONVNET_WG_TILE=$v timeout 120 python tools/layer_bench.py --only conv --reps 5 > "$O/layers_variant_w$v.log" 2>&1
+    echo "wgrad_tile=$v rc=$?"; grep -E "conv[2345]" "$O/layers_variant_w$v.log" | head -12
+  done
+fi
 echo "== the step: default, each new kernel alone, both =="
 for v in "0 0" "$GPW 0" "0 $WGW" "$GPW $WGW"; do
   set -- $v
