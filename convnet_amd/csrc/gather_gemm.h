@@ -109,6 +109,13 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 // The LDS byte address of a pointer into the block's dynamic shared memory (what M0 and the ds instructions take), and the
 // address-space pointer types of the staging builtin.  CONVNET_EMU: the kernels compiled as host code and run on the CPU
 // (tests/emu/hip/hip_runtime.h — test infrastructure for kernels that have not been on hardware yet); LDS is an ordinary array there.
+// Where a wave exchanges data with ITSELF through LDS and relies on its lanes running in lockstep (legal on the hardware: one wave's LDS
+// operations execute in order) the emulation, whose lanes are independent fibers, needs to be told; nothing on the device.
+#ifdef CONVNET_EMU
+#define CHIP_WAVE_LOCKSTEP() emu::wave_sync()
+#else
+#define CHIP_WAVE_LOCKSTEP() ((void)0)
+#endif
 #ifndef CONVNET_EMU
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;

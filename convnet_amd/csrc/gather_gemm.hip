@@ -172,8 +172,6 @@ __global__ __launch_bounds__(WR* WC * 64, (O3 ? 3 : 2)) void gg_kernel(const GGP
   // Ablation on conv4: the register-staged ds_write pass cost 7 % of the kernel.  Out-of-range lanes read
   // the zero page; lanes past the tile are masked off.  (The k-contiguous A tile is padded, not
   // lane-linear, so it keeps the register path.)
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
   constexpr bool GLDS_A = VEC && !A_KCONTIG, GLDS_B = VEC;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   // one staging slot each (it must be a compile-time constant after unrolling: the slot state lives in registers)
@@ -567,8 +565,6 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
     nchunks = (na > 0 && nb2 > 0) ? na * nb2 * (p.KC / BK) : 0;
   }
 
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
   // vmcnt(n) alone (expcnt / lgkmcnt untouched): low four bits in [3:0], high two in [15:14]
   constexpr int kLoads = NA + NB;
   static_assert(kLoads < 64, "vmcnt immediate");
@@ -654,7 +650,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
       ++issued;
       if (skip_a) {
       } else if constexpr (APRE) {
-        const unsigned lda0 = (unsigned)(size_t)(lds_ptr_t)(As + stage * A_STAGE);
+        const unsigned lda0 = lds_addr(As + stage * A_STAGE);
 #pragma unroll
         for (int it = 0; it < NA; it += 4) {
           if (it + 3 < NA) lds_dma4(a_lane, abase, abase, abase, abase, lda0 + 1024u * it);
@@ -677,7 +673,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
         // the uniform base absorbs the same 1 KB on the source side.  No VALU, a quarter of the M0 writes.
         const char* sb = reinterpret_cast<const char*>(src) + (size_t)(cb * BK) * plane_bytes;   // wave-uniform: k-row 0 of the chunk
         const size_t d1 = (size_t)plane_bytes - 1024;
-        const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(Bs + stage * B_STAGE);
+        const unsigned lds0 = lds_addr(Bs + stage * B_STAGE);
 #pragma unroll
         for (int it = 0; it < NB; it += 4) {
           lds_dma4(bvoff, sb, sb + d1, sb + 2 * d1, sb + 3 * d1, lds0 + 1024u * it);
@@ -717,7 +713,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
     auto issue_gk = [&](int stage) __attribute__((always_inline)) {
       if constexpr (APRE) {
         const char* abase = abase0 + a_chunk_bytes * (size_t)gci;
-        const unsigned lda0 = (unsigned)(size_t)(lds_ptr_t)(As + stage * A_STAGE);
+        const unsigned lda0 = lds_addr(As + stage * A_STAGE);
 #pragma unroll
         for (int it = 0; it < NA; it += 4) {
           if (it + 3 < NA) lds_dma4(a_lane, abase, abase, abase, abase, lda0 + 1024u * it);
@@ -729,7 +725,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, ((SPLIT && (MT * (CW / 32) > 6 ||
       }
       const const_u32_ptr_t tk = ktab + 16 * gci;   // wave-uniform
       const char* const sbase = reinterpret_cast<const char*>(src);
-      const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(Bs + stage * B_STAGE);
+      const unsigned lds0 = lds_addr(Bs + stage * B_STAGE);
       if (gfast) {
 #pragma unroll
         for (int it = 0; it < NB; it += 4)
@@ -1078,8 +1074,6 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
 #pragma unroll
     for (int it = 0; it < NB; ++it) b_const[it] = (unsigned)(b_ok[it] ? b_f[it] : 0) * (unsigned)p.M * (unsigned)N + (unsigned)b_n[it];
   }
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto fetch_vec = [&](int buf) {
     const int ysb = w_oy * p.ssy + p.y0, xsb = w_ox * p.ssx + p.x0;
@@ -1273,6 +1267,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_kernel(const WGParams p) {
         for (int u = 0; u < 2; ++u)
 #pragma unroll
           for (int reg = 0; reg < 16; ++reg) ws[(t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh) * 64 + u * 32 + li] = acc[t][u][reg];
+      CHIP_WAVE_LOCKSTEP();
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int idx = it * 64 + lane, row = idx >> 4, c4 = idx & 15;

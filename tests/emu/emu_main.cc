@@ -1,12 +1,16 @@
-// Runs gpp_kernel (calibration: it is green on hardware), gpw_kernel and wgw_kernel FUNCTIONALLY on the CPU — the real kernel sources
-// compiled as host C++ against tests/emu/hip/hip_runtime.h — through their own host launchers (patch_run, wgw_try), on small
-// convolutions, against a straightforward double-precision reference.  Prints one line per case; exit status 0 only if all pass.
+// Runs the library's GEMM-shaped kernels FUNCTIONALLY on the CPU — the real sources (gather_gemm.hip, patch_gemm.hip, wgrad_wide.hip)
+// compiled as host C++ against tests/emu/hip/hip_runtime.h — on small problems against a straightforward double-precision reference:
+// the default kernels through the C ABI (convUp / convDown / convOutp[Bias] / dot: gg_kernel, ggp_kernel incl. its generic-k mode and
+// the stride-class table, wg_kernel in both tile sizes, the slab reduces) as the calibration of the harness — they are green on hardware
+// — and the opt-in ones (gpp_kernel, gpw_kernel and variants, wgw_kernel and variant) through their launchers (patch_run, wgw_try).
+// Prints one line per case; exit status 0 only if all pass.
 #include <hip/hip_runtime.h>
 
 #include <random>
 #include <string>
 #include <vector>
 
+#include "../../convnet_amd/csrc/gather_gemm.hip"
 #include "../../convnet_amd/csrc/patch_gemm.hip"
 #include "../../convnet_amd/csrc/wgrad_wide.hip"
 
@@ -31,29 +35,17 @@ void set_last_error(const char*) {}
 void note_kernel(const char*, double, int, int) {}
 KernelTimer::KernelTimer(const char*, const char*, double, double, double) : slot(-1) {}
 KernelTimer::~KernelTimer() {}
-void gg_reduce_launch(const GGParams& p, size_t dst_elems, int splits, const char*) {   // gg_reduce_kernel on the host
-  const size_t per_row = (size_t)p.DP * p.N;
-  for (size_t i = 0; i < dst_elems; ++i) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += p.partial[(size_t)k * p.slab + i];
-    if (p.scaleTargets != 0.f) s = p.scaleTargets * p.dst[i] + s;
-    if (p.bias) s += p.bias[i / per_row];
-    if (p.relu) s = s > 0.f ? s : 0.f;
-    if (p.mask) s = p.mask[i] > 0.f ? s * p.post_scale : 0.f;
-    p.dst[i] = s;
-  }
-}
-void wg_reduce_launch(const WGParams& p, size_t total, int splits, int, const char*) {   // wg_reduce_kernel on the host
-  const size_t main = (size_t)p.K * p.F;
-  for (size_t i = 0; i < total; ++i) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += p.partial[(size_t)k * total + i];
-    s *= p.scaleOutput;
-    float* d = i < main ? p.dst + i : p.bias_dst + (i - main);
-    *d = p.scaleTargets != 0.f ? p.scaleTargets * (*d) + s : s;
-  }
-}
 }  // namespace chip
+
+extern "C" int sum_by_axis(cudamat* mat, cudamat* target, int axis, float mult, float p) {   // elementwise.hip's, for convOutpBias's fallback: column sums
+  if (axis != 0) std::abort();
+  for (int j = 0; j < mat->size[1]; ++j) {
+    double s = 0;
+    for (int i = 0; i < mat->size[0]; ++i) s += mat->data_device[i + (size_t)mat->size[0] * j];
+    target->data_device[j] = p * target->data_device[j] + mult * (float)s;
+  }
+  return 0;
+}
 
 using namespace chip;
 
@@ -209,10 +201,155 @@ static void wgrad_case(const Geo& g, bool with_bias, float scaleTargets, float s
           err, ok);
 }
 
+// ---- the default kernels through the C ABI ------------------------------------------------------------------------------------------
+static cudamat mat(float* d, int rows, int cols) {
+  cudamat m{};
+  m.data_device = d; m.on_device = 1; m.size[0] = rows; m.size[1] = cols; m.owns_data = 0;
+  return m;
+}
+static ConvDesc desc(const Geo& g) {
+  ConvDesc d{};
+  d.num_input_channels = g.C; d.num_output_channels = g.F; d.kernel_size_y = g.Ky; d.kernel_size_x = g.Kx; d.kernel_size_t = 1;
+  d.stride_y = g.sy; d.stride_x = g.sx; d.stride_t = 1; d.padding_y = -g.pad; d.padding_x = -g.pad; d.num_groups = 1;
+  return d;
+}
+static std::string gname(const Geo& g) {
+  return "N" + std::to_string(g.N) + " C" + std::to_string(g.C) + " " + std::to_string(g.H) + "x" + std::to_string(g.W) + " F" + std::to_string(g.F) + " k" +
+         std::to_string(g.Ky) + " s" + std::to_string(g.sy) + " p" + std::to_string(g.pad);
+}
+static void abi_conv_case(const Geo& g, const char* which) {
+  convnet_hip_set_patch_mode(0);
+  convnet_hip_set_wgrad_tile(0);
+  const int My = g.My(), Mx = g.Mx(), TYX = g.Ky * g.Kx, K = g.C * TYX;
+  auto xv = rnd((size_t)g.C * g.H * g.W * g.N, 11), wv = rnd((size_t)g.F * K, 12), yv = rnd((size_t)g.F * My * Mx * g.N, 13), bv = rnd(g.F, 14);
+  float *x = al16(xv), *w = al16(wv), *y = al16(yv), *b = al16(bv);
+  cudamat mx = mat(x, g.N, g.H * g.W * g.C), mw = mat(w, g.F, K), my = mat(y, g.N, My * Mx * g.F), mb = mat(b, 1, g.F);
+  Shape4D sx{{g.N, g.W, g.H, g.C}}, sw{{g.F, g.Kx, g.Ky, g.C}}, sy{{g.N, Mx, My, g.F}};
+  const std::string what = which;
+  if (what == "up") {
+    std::vector<double> ref((size_t)g.F * My * Mx * g.N);
+    for (int f = 0; f < g.F; ++f)
+      for (int oy = 0; oy < My; ++oy)
+        for (int ox = 0; ox < Mx; ++ox)
+          for (int n = 0; n < g.N; ++n) {
+            double s = 0;
+            for (int c = 0; c < g.C; ++c)
+              for (int a = 0; a < g.Ky; ++a)
+                for (int bb = 0; bb < g.Kx; ++bb) {
+                  const int ys = oy * g.sy - g.pad + a, xs = ox * g.sx - g.pad + bb;
+                  if (ys < 0 || ys >= g.H || xs < 0 || xs >= g.W) continue;
+                  s += (double)x[((size_t)(c * g.H + ys) * g.W + xs) * g.N + n] * w[f + (size_t)g.F * (a * g.Kx + bb + TYX * c)];
+                }
+            ref[((size_t)(f * My + oy) * Mx + ox) * g.N + n] = s;
+          }
+    convUp(&mx, &mw, &my, &sx, &sw, &sy, desc(g), 0.f);
+    verdict("abi convUp " + gname(g), rel_err(y, ref), true);
+  } else if (what == "down") {
+    std::vector<double> ref((size_t)g.C * g.H * g.W * g.N);
+    for (int c = 0; c < g.C; ++c)
+      for (int iy = 0; iy < g.H; ++iy)
+        for (int ix = 0; ix < g.W; ++ix)
+          for (int n = 0; n < g.N; ++n) {
+            double s = 0;
+            for (int f = 0; f < g.F; ++f)
+              for (int a = 0; a < g.Ky; ++a)
+                for (int bb = 0; bb < g.Kx; ++bb) {
+                  const int ty = iy + g.pad - a, tx = ix + g.pad - bb;
+                  if (ty < 0 || tx < 0 || ty % g.sy || tx % g.sx) continue;
+                  const int oy = ty / g.sy, ox = tx / g.sx;
+                  if (oy >= My || ox >= Mx) continue;
+                  s += (double)y[((size_t)(f * My + oy) * Mx + ox) * g.N + n] * w[f + (size_t)g.F * (a * g.Kx + bb + TYX * c)];
+                }
+            ref[((size_t)(c * g.H + iy) * g.W + ix) * g.N + n] = s;
+          }
+    convDown(&my, &mw, &mx, &sy, &sw, &sx, desc(g), 0.f);
+    verdict("abi convDown " + gname(g), rel_err(x, ref), true);
+  } else {   // "outp": weight gradients + bias gradient
+    std::vector<double> ref((size_t)g.F * K), refb(g.F);
+    for (int f = 0; f < g.F; ++f) {
+      for (int c = 0; c < g.C; ++c)
+        for (int a = 0; a < g.Ky; ++a)
+          for (int bb = 0; bb < g.Kx; ++bb) {
+            double s = 0;
+            for (int oy = 0; oy < My; ++oy)
+              for (int ox = 0; ox < Mx; ++ox) {
+                const int ys = oy * g.sy - g.pad + a, xs = ox * g.sx - g.pad + bb;
+                if (ys < 0 || ys >= g.H || xs < 0 || xs >= g.W) continue;
+                for (int n = 0; n < g.N; ++n)
+                  s += (double)x[((size_t)(c * g.H + ys) * g.W + xs) * g.N + n] * y[((size_t)(f * My + oy) * Mx + ox) * g.N + n];
+              }
+            const size_t i = f + (size_t)g.F * (a * g.Kx + bb + TYX * c);
+            ref[i] = 1.0 * w[i] + 0.5 * s;
+          }
+      double sb = 0;
+      for (size_t i = 0; i < (size_t)My * Mx * g.N; ++i) sb += y[(size_t)f * My * Mx * g.N + i];
+      refb[f] = 1.0 * b[f] + 0.5 * sb;
+    }
+    convOutpBias(&mx, &my, &mw, &mb, &sx, &sy, &sw, desc(g), 1.f, 0.5f);
+    verdict("abi convOutpBias " + gname(g), std::max(rel_err(w, ref), rel_err(b, refb)), true);
+  }
+}
+// the three products of an FC layer (fc_edge.cc:54-74): dot(mat1, mat2, target, beta, alpha) with cudamat's is_trans flags
+static void abi_dot_case(int N, int D, int F) {
+  auto xv = rnd((size_t)N * D, 21), wv = rnd((size_t)F * D, 22), dv = rnd((size_t)N * F, 23), tv = rnd((size_t)std::max(N, F) * std::max(D, F), 24);
+  float *x = al16(xv), *w = al16(wv), *dy = al16(dv), *t = al16(tv);
+  double worst = 0;
+  {   // out(N,F) = in(N,D) * W(F,D)^T
+    cudamat mx = mat(x, N, D), mw = mat(w, F, D), mt = mat(t, N, F);
+    mw.is_trans = 1;
+    std::vector<double> ref((size_t)N * F);
+    for (int n = 0; n < N; ++n)
+      for (int f = 0; f < F; ++f) {
+        double s = 0;
+        for (int d = 0; d < D; ++d) s += (double)x[n + (size_t)N * d] * w[f + (size_t)F * d];
+        ref[n + (size_t)N * f] = s;
+      }
+    if (dot(&mx, &mw, &mt, 0.f, 1.f)) worst = 1;
+    worst = std::max(worst, rel_err(t, ref));
+  }
+  {   // d_in(N,D) = d_out(N,F) * W(F,D)
+    cudamat md = mat(dy, N, F), mw = mat(w, F, D), mt = mat(t, N, D);
+    std::vector<double> ref((size_t)N * D);
+    for (int n = 0; n < N; ++n)
+      for (int d = 0; d < D; ++d) {
+        double s = 0;
+        for (int f = 0; f < F; ++f) s += (double)dy[n + (size_t)N * f] * w[f + (size_t)F * d];
+        ref[n + (size_t)N * d] = s;
+      }
+    if (dot(&md, &mw, &mt, 0.f, 1.f)) worst = 1;
+    worst = std::max(worst, rel_err(t, ref));
+  }
+  {   // dW(F,D) = d_out(N,F)^T * in(N,D) / N
+    cudamat md = mat(dy, N, F), mx = mat(x, N, D), mt = mat(t, F, D);
+    md.is_trans = 1;
+    std::vector<double> ref((size_t)F * D);
+    for (int f = 0; f < F; ++f)
+      for (int d = 0; d < D; ++d) {
+        double s = 0;
+        for (int n = 0; n < N; ++n) s += (double)dy[n + (size_t)N * f] * x[n + (size_t)N * d];
+        ref[f + (size_t)F * d] = s / N;
+      }
+    if (dot(&md, &mx, &mt, 0.f, 1.f / N)) worst = 1;
+    worst = std::max(worst, rel_err(t, ref));
+  }
+  verdict("abi dot NT / NN / TN N" + std::to_string(N) + " D" + std::to_string(D) + " F" + std::to_string(F), worst, true);
+}
+
 int main(int argc, char** argv) {
-  const std::string what = argc > 1 ? argv[1] : "quick";   // gpp | gpw | wgw | quick (a subset of each, ~1 minute) | all
+  const std::string what = argc > 1 ? argv[1] : "quick";   // abi | gpp | gpw | gpwvar | gpwtail | wgw | wgwvar | quick (a subset of each, ~1 minute) | all
   const bool all = what == "all", quick = what == "quick";   // ("all" does not include gpwtail: its 8-slot chip is a process-wide setting)
-  if (what == "gpp" || all || quick) {   // calibration of the harness on a kernel that is green on hardware
+  if (what == "abi" || all || quick) {   // the default kernels through the C ABI: the calibration of the harness (green on hardware)
+    abi_conv_case(Geo{64, 16, 9, 9, 128, 3, 3, 1, 1, 1}, "up");      // ggp_kernel<2,2,2,128>, pre-split filter planes
+    abi_conv_case(Geo{32, 16, 9, 9, 128, 3, 3, 1, 1, 1}, "outp");    // wg_kernel<2,2,2,2>, K = 144: bias row in the second k tile
+    if (!quick) {
+      abi_conv_case(Geo{64, 3, 15, 15, 96, 7, 7, 2, 2, 1}, "up");      // conv1 type: generic-k order on ggp_kernel<1,4,3,64>
+      abi_conv_case(Geo{64, 128, 9, 9, 32, 3, 3, 1, 1, 1}, "down");    // one stride class
+      abi_conv_case(Geo{64, 96, 11, 11, 32, 5, 5, 2, 2, 0}, "down");   // conv2 type: four stride classes in one launch
+      abi_conv_case(Geo{32, 3, 15, 15, 96, 7, 7, 2, 2, 1}, "outp");    // conv1 type: the 160 x 96 tile of 16 x 16 MFMAs, bias row in a padding row
+      abi_dot_case(64, 256, 128);
+    }
+  }
+  if (what == "gpp" || all || quick) {   // an opt-in kernel that is green on hardware too
     fprop_case(Geo{64, 16, 9, 9, 96, 3, 3, 1, 1, 1}, 1, "gpp(raw)");
     if (!quick) dgrad_case(Geo{64, 96, 6, 6, 16, 3, 3, 1, 1, 1}, 1, "gpp(raw)");
   }

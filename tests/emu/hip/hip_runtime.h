@@ -217,10 +217,74 @@ inline C16 mfma_32x32x16(const A8& a, const A8& b, C16 c) {
   wave_sync();
   return c;
 }
+// v_mfma_f32_32x32x2_f32: lane = li + 32*lh supplies A[row li][k = lh] and B[k = lh][column li]; D as above
+template <typename C16>
+inline C16 mfma_32x32x2_f32(float a, float b, C16 c) {
+  Fiber* f = cur();
+  Wave& w = f->blk->waves[f->wave];
+  std::memcpy(w.slot[f->lane], &a, 4);
+  std::memcpy(w.slot[f->lane] + 4, &b, 4);
+  wave_sync();
+  const int li = f->lane & 31, lh = f->lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    float s = 0.f;
+    for (int k = 0; k < 2; ++k) {
+      float av, bv;
+      std::memcpy(&av, w.slot[row + 32 * k], 4);
+      std::memcpy(&bv, w.slot[li + 32 * k] + 4, 4);
+      s += av * bv;
+    }
+    c[r] += s;
+  }
+  wave_sync();
+  return c;
+}
+// v_mfma_f32_16x16x4_f32: lane = li + 16*lh (lh = k 0..3); D register r of lane (li, lh) = row 4*lh + r, column li
+template <typename C4>
+inline C4 mfma_16x16x4_f32(float a, float b, C4 c) {
+  Fiber* f = cur();
+  Wave& w = f->blk->waves[f->wave];
+  std::memcpy(w.slot[f->lane], &a, 4);
+  std::memcpy(w.slot[f->lane] + 4, &b, 4);
+  wave_sync();
+  const int li = f->lane & 15, lh = f->lane >> 4;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * lh + r;
+    float s = 0.f;
+    for (int k = 0; k < 4; ++k) {
+      float av, bv;
+      std::memcpy(&av, w.slot[row + 16 * k], 4);
+      std::memcpy(&bv, w.slot[li + 16 * k] + 4, 4);
+      s += av * bv;
+    }
+    c[r] += s;
+  }
+  wave_sync();
+  return c;
+}
+// v_mfma_f32_16x16x32_bf16: lane = li + 16*lh (lh 0..3) holds row / column li, k-slots 8*lh .. 8*lh + 7; D register r = row 4*lh + r, column li
 template <typename A8, typename C4>
-inline C4 mfma_16x16x32(const A8&, const A8&, C4 c) {
-  std::fprintf(stderr, "emu: v_mfma_f32_16x16x32_bf16 is not modelled\n");
-  std::abort();
+inline C4 mfma_16x16x32(const A8& a, const A8& b, C4 c) {
+  static_assert(sizeof(A8) == 16, "8 bf16");
+  Fiber* f = cur();
+  Wave& w = f->blk->waves[f->wave];
+  std::memcpy(w.slot[f->lane], &a, 16);
+  std::memcpy(w.slot[f->lane] + 16, &b, 16);
+  wave_sync();
+  const int li = f->lane & 15, lh = f->lane >> 4;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * lh + r;
+    float s = 0.f;
+    for (int kg = 0; kg < 4; ++kg) {
+      unsigned short av[8], bv[8];
+      std::memcpy(av, w.slot[row + 16 * kg], 16);
+      std::memcpy(bv, w.slot[li + 16 * kg] + 16, 16);
+      for (int e = 0; e < 8; ++e) s += bf16_to_float(av[e]) * bf16_to_float(bv[e]);
+    }
+    c[r] += s;
+  }
+  wave_sync();
   return c;
 }
 template <typename G, typename L>
@@ -248,6 +312,9 @@ inline int lane_id() { return cur()->lane; }
 #define __builtin_amdgcn_s_memtime() 0ull
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu::mfma_16x16x32(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2_f32(a, b, c)
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu::mfma_16x16x4_f32(a, b, c)
+#define __builtin_amdgcn_s_getreg(x) 0u
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu::global_load_lds(g, l, size)
 
 inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
@@ -259,3 +326,9 @@ inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
 inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
 inline size_t min(size_t a, size_t b) { return a < b ? a : b; }
 inline size_t max(size_t a, size_t b) { return a > b ? a : b; }
+inline unsigned long long min(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
+inline unsigned long long max(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }

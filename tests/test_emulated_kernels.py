@@ -1,10 +1,13 @@
-"""gpw_kernel and wgw_kernel — written after the last hardware run of their round — executed FUNCTIONALLY on the CPU: the real kernel
-sources (convnet_amd/csrc/patch_gemm.hip, wgrad_wide.hip) compiled as host C++ against tests/emu/hip/hip_runtime.h (every thread of a
-block a fiber; wave collectives, the bf16 MFMA in the register layout the kernels assume, LDS-DMA as an immediate copy) and run through
-their own host launchers on small convolutions against a double-precision reference (tests/emu/emu_main.cc).  The harness is calibrated
-in the same run on gpp_kernel, which is green on hardware.  No GPU; not a product path.  What this cannot see: timing, late-landing loads
-(tests/test_patch_wide_cpu.py / test_wgrad_wide_cpu.py model those), the M0 range above 84 KB, instruction hazards.
-CONVNET_EMU_ALL=1 runs every case (~2 minutes) instead of one or two per kernel (~1 minute)."""
+"""The library's GEMM-shaped kernels executed FUNCTIONALLY on the CPU: the real kernel sources (convnet_amd/csrc/gather_gemm.hip,
+patch_gemm.hip, wgrad_wide.hip) compiled as host C++ against tests/emu/hip/hip_runtime.h (every thread of a block a fiber; wave
+collectives, the MFMAs in the register layouts the kernels assume, LDS-DMA as an immediate copy) and run on small problems against a
+double-precision reference (tests/emu/emu_main.cc).
+* The default kernels, through the C ABI (convUp / convDown / convOutpBias / dot: ggp_kernel incl. its generic-k mode and the
+  stride-class table, gg_kernel, wg_kernel in both tile sizes with the bias row, the slab reduces).  They are green on hardware: here
+  they are the calibration of the harness, and a functional check of the product kernels that needs no GPU.
+* gpw_kernel and wgw_kernel (and their variants) — written after the last hardware run of their round — through their own launchers.
+No GPU; not a product path.  What this cannot see: timing, late-landing loads (tests/test_patch_wide_cpu.py / test_wgrad_wide_cpu.py model
+those), the M0 range above 84 KB, instruction hazards.  CONVNET_EMU_ALL=1 runs every case (~5 minutes) instead of a subset (~1.5)."""
 import os
 import shutil
 import subprocess
@@ -39,7 +42,8 @@ def test_wide_kernels_run_correctly_in_emulation(emu_binary):
     lines = r.stdout.strip().splitlines()
     print(r.stdout)
     assert r.returncode == 0 and lines and lines[-1] == "ALL PASSED", r.stdout + r.stderr
-    # the calibration case and both kernels really ran
+    # the calibration cases and both new kernels really ran
+    assert any(l.startswith("PASS abi convUp") for l in lines) and any(l.startswith("PASS abi convOutpBias") for l in lines)
     assert any(l.startswith("PASS gpp(raw)") for l in lines) and any(l.startswith("PASS gpw fprop") for l in lines)
     assert any(l.startswith("PASS gpw dgrad") for l in lines) and any(l.startswith("PASS wgw wgrad") for l in lines)
 
