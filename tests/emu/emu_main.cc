@@ -10,12 +10,12 @@
 #include <string>
 #include <vector>
 
-#include "../../convnet_amd/csrc/gather_gemm.hip"
-#include "../../convnet_amd/csrc/patch_gemm.hip"
-#include "../../convnet_amd/csrc/wgrad_wide.hip"
+#include "../../convnet_amd/csrc/gather_gemm.h"   // (the .hip files are compiled one by one against the same stand-in header and linked in:
+                                                  // tests/test_emulated_kernels.py)
 
 namespace chip {
 alignas(16) float smem[40960 + 4096];   // 160 KB + slack: the block's LDS
+alignas(16) float rn_smem[40960];          // pool_norm.hip names its dynamic LDS array differently
 hipStream_t stream() { return nullptr; }
 static std::vector<char> g_ws[3];
 static void* arena(int i, size_t bytes) {
@@ -37,13 +37,8 @@ KernelTimer::KernelTimer(const char*, const char*, double, double, double) : slo
 KernelTimer::~KernelTimer() {}
 }  // namespace chip
 
-extern "C" int sum_by_axis(cudamat* mat, cudamat* target, int axis, float mult, float p) {   // elementwise.hip's, for convOutpBias's fallback: column sums
-  if (axis != 0) std::abort();
-  for (int j = 0; j < mat->size[1]; ++j) {
-    double s = 0;
-    for (int i = 0; i < mat->size[0]; ++i) s += mat->data_device[i + (size_t)mat->size[0] * j];
-    target->data_device[j] = p * target->data_device[j] + mult * (float)s;
-  }
+extern "C" int copy_on_device(cudamat* src, cudamat* dst) {   // state.hip's
+  std::memcpy(dst->data_device, src->data_device, sizeof(float) * (size_t)src->size[0] * src->size[1]);
   return 0;
 }
 
@@ -335,6 +330,63 @@ static void abi_dot_case(int N, int D, int F) {
   verdict("abi dot NT / NN / TN N" + std::to_string(N) + " D" + std::to_string(D) + " F" + std::to_string(F), worst, true);
 }
 
+// ---- the HBM-bound kernels through the C ABI, against the CPU oracle (oracle/liboracle.so: the C restatement of the reference) ---------
+extern "C" {
+void oracle_max_pool(const float*, float*, int N, int C, int H, int W, int Ky, int Kx, int sy, int sx, int pady, int padx, int My, int Mx, float scaleTargets, float scaleOutput);
+void oracle_max_pool_undo(const float* images, const float* maxGrads, const float* maxActs, float* targets, int N, int C, int H, int W, int Ky, int Kx, int sy,
+                          int sx, int pady, int padx, int My, int Mx, float scaleTargets);
+void oracle_rnorm(const float* images, float* targets, int num_locs, int C, int sizeF, float addScale, float powScale, int blocked);
+void oracle_rnorm_undo(const float* outGrads, const float* inputs, float* targets, int num_locs, int C, int sizeF, float addScale, float powScale, int blocked);
+void oracle_sgd_step(float* grad, float* param, float* history, int rows, int cols, float l2_decay, float gradient_clip, float epsilon, float momentum,
+                     float norm_limit, float norm_constraint);
+}
+static double rel_err_f(const float* a, const float* b, size_t n) {
+  std::vector<double> r(b, b + n);
+  return rel_err(a, r);
+}
+static void pool_case(int N, int C, int H, int K, int st) {
+  const int M = (H - K) / st + 1;
+  Geo g{N, C, H, H, C, K, K, st, st, 0};
+  auto xv = rnd((size_t)C * H * H * N, 31), yv = rnd((size_t)C * M * M * N, 32), gv = rnd((size_t)C * M * M * N, 33), dv = rnd((size_t)C * H * H * N, 34);
+  float *x = al16(xv), *y = al16(yv), *gr = al16(gv), *dx = al16(dv);
+  std::vector<float> yr((size_t)C * M * M * N), dr((size_t)C * H * H * N);
+  cudamat mx = mat(x, N, H * H * C), my = mat(y, N, M * M * C), mg = mat(gr, N, M * M * C), md = mat(dx, N, H * H * C);
+  Shape4D sx{{N, H, H, C}}, sy{{N, M, M, C}};
+  MaxPoolGemm(&mx, &my, &sx, &sy, desc(g), 0.f, 1.f);
+  oracle_max_pool(x, yr.data(), N, C, H, H, K, K, st, st, 0, 0, M, M, 0.f, 1.f);
+  const double e1 = rel_err_f(y, yr.data(), yr.size());
+  MaxPoolUndoGemm(&mx, &mg, &my, &md, &sx, &sy, desc(g), 0.f);
+  oracle_max_pool_undo(x, gr, yr.data(), dr.data(), N, C, H, H, K, K, st, st, 0, 0, M, M, 0.f);
+  const double e2 = rel_err_f(dx, dr.data(), dr.size());
+  verdict("abi MaxPool + MaxPoolUndo N" + std::to_string(N) + " C" + std::to_string(C) + " " + std::to_string(H) + "x" + std::to_string(H) + " k" + std::to_string(K) +
+              " s" + std::to_string(st),
+          std::max(e1, e2), true);
+}
+static void rnorm_case(int N, int C, int HW, int sizeF) {
+  const int locs = HW * N;
+  auto xv = rnd((size_t)C * locs, 41), yv = rnd((size_t)C * locs, 42), gv = rnd((size_t)C * locs, 43), dv = rnd((size_t)C * locs, 44);
+  float *x = al16(xv), *y = al16(yv), *gr = al16(gv), *dx = al16(dv);
+  std::vector<float> yr((size_t)C * locs), dr((size_t)C * locs);
+  cudamat mx = mat(x, N, HW * C), my = mat(y, N, HW * C), mg = mat(gr, N, HW * C), md = mat(dx, N, HW * C);
+  ResponseNormCrossMapGemm(&mx, &my, C, sizeF, 0.001f, 0.75f, false);
+  oracle_rnorm(x, yr.data(), locs, C, sizeF, 0.001f, 0.75f, 0);
+  const double e1 = rel_err_f(y, yr.data(), yr.size());
+  ResponseNormCrossMapUndoGemm(&mg, &mx, &md, C, sizeF, 0.001f, 0.75f, false);
+  oracle_rnorm_undo(gr, x, dr.data(), locs, C, sizeF, 0.001f, 0.75f, 0);
+  const double e2 = rel_err_f(dx, dr.data(), dr.size());
+  verdict("abi ResponseNormCrossMap + Undo N" + std::to_string(N) + " C" + std::to_string(C) + " pixels " + std::to_string(HW) + " size " + std::to_string(sizeF), std::max(e1, e2), true);
+}
+static void sgd_case(int rows, int cols) {
+  const size_t n = (size_t)rows * cols;
+  auto gv = rnd(n, 51), pv = rnd(n, 52), hv = rnd(n, 53);
+  float *g = al16(gv), *p = al16(pv), *h = al16(hv);
+  std::vector<float> g2(g, g + n), p2(p, p + n), h2(h, h + n);
+  cudamat mg = mat(g, rows, cols), mp = mat(p, rows, cols), mh = mat(h, rows, cols);
+  const int rc = sgd_momentum_step(&mg, &mp, &mh, 0.0005f, 0.f, 0.01f, 0.9f);
+  oracle_sgd_step(g2.data(), p2.data(), h2.data(), rows, cols, 0.0005f, 0.f, 0.01f, 0.9f, 0.f, 0.f);
+  verdict("abi sgd_momentum_step " + std::to_string(rows) + " x " + std::to_string(cols), std::max(rel_err_f(p, p2.data(), n), rel_err_f(h, h2.data(), n)), rc == 0);
+}
+
 int main(int argc, char** argv) {
   const std::string what = argc > 1 ? argv[1] : "quick";   // abi | gpp | gpw | gpwvar | gpwtail | wgw | wgwvar | quick (a subset of each, ~1 minute) | all
   const bool all = what == "all", quick = what == "quick";   // ("all" does not include gpwtail: its 8-slot chip is a process-wide setting)
@@ -347,6 +399,11 @@ int main(int argc, char** argv) {
       abi_conv_case(Geo{64, 96, 11, 11, 32, 5, 5, 2, 2, 0}, "down");   // conv2 type: four stride classes in one launch
       abi_conv_case(Geo{32, 3, 15, 15, 96, 7, 7, 2, 2, 1}, "outp");    // conv1 type: the 160 x 96 tile of 16 x 16 MFMAs, bias row in a padding row
       abi_dot_case(64, 256, 128);
+      pool_case(32, 32, 21, 3, 2);        // pool1 type (3 x 3 stride 2; 441 pixels: the 2 x 2-block undo kernel)
+      pool_case(64, 16, 7, 3, 2);         // a small map: the per-output undo kernel
+      rnorm_case(32, 96, 25, 5);          // rnorm1 type: 96 channels, window 5
+      rnorm_case(16, 256, 9, 5);
+      sgd_case(96, 147);
     }
   }
   if (what == "gpp" || all || quick) {   // an opt-in kernel that is green on hardware too

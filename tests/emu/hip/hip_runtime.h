@@ -112,10 +112,11 @@ inline void trampoline() {
 }
 inline void launch(dim3 grid, dim3 block, size_t /*lds*/, const std::function<void()>& fn) {
   constexpr size_t kStack = 256 * 1024;
-  for (unsigned by = 0; by < grid.y; ++by)
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+   for (unsigned by = 0; by < grid.y; ++by)
     for (unsigned bx = 0; bx < grid.x; ++bx) {
       Block b;
-      b.bid = dim3(bx, by);
+      b.bid = dim3(bx, by, bz);
       b.bdim = block;
       b.gdim = grid;
       b.fn = &fn;
@@ -292,6 +293,19 @@ inline void global_load_lds(G g, L l, int size) {   // each lane: `size` bytes f
   std::memcpy((char*)(uintptr_t)l + (size_t)cur()->lane * size, (const void*)(uintptr_t)g, (size_t)size);
 }
 inline int lane_id() { return cur()->lane; }
+template <typename T>
+inline T shfl_xor(T v, int mask) { return publish_and_read(v, (cur()->lane ^ mask) & 63); }
+inline int syncthreads_or(int pred) {
+  Block* b = cur()->blk;
+  static int acc[2];
+  const unsigned g = b->barrier_gen & 1;
+  if (pred) acc[g] = 1;
+  block_barrier();
+  const int r = acc[g];
+  block_barrier();
+  acc[g] = 0;   // every fiber clears it after both barriers: nobody reads this generation's slot again before the next use two barriers on
+  return r;
+}
 
 }  // namespace emu
 
@@ -317,6 +331,16 @@ inline int lane_id() { return cur()->lane; }
 #define __builtin_amdgcn_s_getreg(x) 0u
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu::global_load_lds(g, l, size)
 
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) { return emu::shfl_xor(v, mask); }   // (width 64 only)
+#define __syncthreads_or(p) emu::syncthreads_or(p)
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }   // one OS thread: fibers never interleave inside this
+inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+inline float __log2f(float x) { return std::log2(x); }
+inline float __powf(float x, float y) { return std::pow(x, y); }
+inline float __expf(float x) { return std::exp(x); }
 inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
 // (fabsf / copysignf: the C library's, via <cmath>)
@@ -332,3 +356,4 @@ enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMe
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }

@@ -6,6 +6,8 @@ double-precision reference (tests/emu/emu_main.cc).
   stride-class table, gg_kernel, wg_kernel in both tile sizes with the bias row, the slab reduces).  They are green on hardware: here
   they are the calibration of the harness, and a functional check of the product kernels that needs no GPU.
 * gpw_kernel and wgw_kernel (and their variants) — written after the last hardware run of their round — through their own launchers.
+* The HBM-bound kernels of the path through the C ABI against the CPU oracle (oracle/liboracle.so): max pooling and its undo (both
+  undo kernels), cross-map response normalisation and its undo, the fused SGD step.
 No GPU; not a product path.  What this cannot see: timing, late-landing loads (tests/test_patch_wide_cpu.py / test_wgrad_wide_cpu.py model
 those), the M0 range above 84 KB, instruction hazards.  CONVNET_EMU_ALL=1 runs every case (~5 minutes) instead of a subset (~1.5)."""
 import os
@@ -25,14 +27,26 @@ def _clang():
     return None
 
 
+SOURCES = ["gather_gemm.hip", "patch_gemm.hip", "wgrad_wide.hip", "pool_norm.hip", "elementwise.hip"]
+
+
 @pytest.fixture(scope="module")
 def emu_binary(tmp_path_factory):
     cc = _clang()
     if not cc:
         pytest.skip("no clang++ (the kernels use clang's vector extensions and __bf16)")
-    exe = tmp_path_factory.mktemp("emu") / "emu_main"
-    subprocess.run([cc, "-std=c++17", "-O1", "-x", "c++", "-I", os.path.join(HERE, "emu"), "-I", os.path.join(ROOT, "convnet_amd", "csrc"), "-Wno-everything",
-                    os.path.join(HERE, "emu", "emu_main.cc"), "-o", str(exe)], check=True)
+    oracle_dir = os.path.join(ROOT, "oracle")
+    if not os.path.exists(os.path.join(oracle_dir, "liboracle.so")):
+        pytest.skip("oracle/liboracle.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    d = tmp_path_factory.mktemp("emu")
+    flags = ["-std=c++17", "-O1", "-x", "c++", "-I", os.path.join(HERE, "emu"), "-I", os.path.join(ROOT, "convnet_amd", "csrc"), "-Wno-everything"]
+    jobs = [(os.path.join(ROOT, "convnet_amd", "csrc", f), str(d / (f + ".o"))) for f in SOURCES] + [(os.path.join(HERE, "emu", "emu_main.cc"), str(d / "emu_main.o"))]
+    procs = [subprocess.Popen([cc, *flags, "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for src, obj in jobs]
+    for p, (src, _) in zip(procs, jobs):
+        out, _ = p.communicate()
+        assert p.returncode == 0, src + "\n" + out
+    exe = d / "emu_main"
+    subprocess.run([cc, *[o for _, o in jobs], "-o", str(exe), "-L", oracle_dir, "-loracle", "-Wl,-rpath," + oracle_dir], check=True)
     return str(exe)
 
 
