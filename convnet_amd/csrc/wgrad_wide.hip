@@ -252,10 +252,48 @@ __global__ __launch_bounds__(256, 1) void wgw_kernel(const WGParams p) {
     __builtin_amdgcn_s_waitcnt(0x0070);   // (the zero-page loads past the end) before the LDS is released
   }
 
-  // ---- write-out: wg_kernel's direct form (a lane holds one filter column and 16 k-rows per tile) --------------------------------
+  // ---- write-out --------------------------------------------------------------------------------------------------------------------
   const bool fin = p.splits == 1;
   const int KB = p.K + (p.bias_dst ? 1 : 0);
   float* out = fin ? p.dst : p.partial + (size_t)split * KB * p.F;
+  if (p.wide) {
+    // As wg_kernel's wide write-out, for the bigger tile: the accumulator layout gives a lane ONE filter column and 16 k-rows per
+    // 32 x 32 tile — 256 four-byte stores per lane here, and stores are issue-bound when every wave of the chip stores at once
+    // (MI355X_MICROARCH.md: hundreds of cycles per store instruction in a store tail).  Each wave transposes its 128 x FW sub-tile
+    // through its quarter of the (now idle) stages in two passes of 64 rows — ds_write_b32 with the lanes along f, ds_read_b128 along
+    // f — and stores 16 bytes per lane: 64 stores instead of 256.  One wave's LDS operations execute in order: no barrier inside.
+    constexpr int FW = 32 * NTL, Q = FW / 4;                        // sub-tile width in floats / in 16-byte pieces
+    constexpr int WS = (2 * (A_STAGE + B_STAGE)) / 4;               // floats of LDS per wave
+    static_assert(64 * FW <= WS, "half a sub-tile per pass");
+    __syncthreads();                                                 // every wave is done with the stages
+    float* ws = smem + wave * WS;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+        for (int u = 0; u < NTL; ++u)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) ws[(tl * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh) * FW + u * 32 + li] = acc[2 * pass + tl][u][reg];
+      CHIP_WAVE_LOCKSTEP();
+#pragma unroll
+      for (int it = 0; it < Q; ++it) {                               // 64 rows x Q pieces = 64 * Q / 64 lanes
+        const int idx = it * 64 + lane, row = idx / Q, c4 = idx - row * Q;
+        f32x4 v = ld4(ws + row * FW + 4 * c4);
+        const int k = kc0 + wm * 128 + pass * 64 + row, f = f0 + wn * FW + 4 * c4;
+        if (k >= KB || f >= p.F) continue;
+        float* dp = (fin && k == p.K) ? p.bias_dst + f : out + (size_t)k * p.F + f;
+        if (fin) {
+          v = v * p.scaleOutput;
+          if (p.scaleTargets != 0.f) v = p.scaleTargets * ld4(dp) + v;
+        }
+        st4(dp, v);
+      }
+      CHIP_WAVE_LOCKSTEP();                                          // (the next pass overwrites ws)
+    }
+    return;
+  }
+  // direct form (a lane holds one filter column and 16 k-rows per tile): filter counts that are not a multiple of four, unaligned targets
 #pragma unroll
   for (int u = 0; u < NTL; ++u) {
     const int f = f0 + (wn * NTL + u) * 32 + li;
@@ -299,7 +337,7 @@ void wgw_launch(WGParams& p, const char* op, double flops, double exec) {
   if (p.bias_dst && divup(p.K + 1, KT) != p.k_tiles) p.bias_dst = nullptr;   // no padding row to spare: caller sums separately
   p.f_tiles = divup(p.F, FT);
   p.zero = zero_page();
-  p.wide = 0;
+  p.wide = (p.F % 4 == 0 && (reinterpret_cast<uintptr_t>(p.dst) & 15) == 0 && (!p.bias_dst || (reinterpret_cast<uintptr_t>(p.bias_dst) & 15) == 0)) ? 1 : 0;   // 16-byte write-out
   const int tiles = p.k_tiles * p.f_tiles;
   const size_t total = (size_t)(p.K + (p.bias_dst ? 1 : 0)) * p.F;
   // one full round of resident blocks (ONE per CU), as wg_launch_cfg: floor, not ceil
@@ -313,6 +351,9 @@ void wgw_launch(WGParams& p, const char* op, double flops, double exec) {
     if ((size_t)splits > max_by_bytes) splits = (int)max_by_bytes;
     if (splits < 1) splits = 1;
   }
+#ifdef CONVNET_EMU
+  if (const char* e = getenv("CONVNET_EMU_WG_SPLITS")) splits = atoi(e);   // tests/emu: reach the single-block-per-tile epilogue at emulation sizes
+#endif
   p.chunks_per_split = divup(p.chunks_total, splits);
   splits = divup(p.chunks_total, p.chunks_per_split);
   p.splits = splits;

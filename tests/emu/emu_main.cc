@@ -388,7 +388,7 @@ static void sgd_case(int rows, int cols) {
 }
 
 int main(int argc, char** argv) {
-  const std::string what = argc > 1 ? argv[1] : "quick";   // abi | gpp | gpw | gpwvar | gpwtail | wgw | wgwvar | quick (a subset of each, ~1 minute) | all
+  const std::string what = argc > 1 ? argv[1] : "quick";   // abi | gpp | gpw | gpwvar | gpwtail | wgw | wgwvar | wgwfin | quick (a subset of each, ~1 minute) | all
   const bool all = what == "all", quick = what == "quick";   // ("all" does not include gpwtail: its 8-slot chip is a process-wide setting)
   if (what == "abi" || all || quick) {   // the default kernels through the C ABI: the calibration of the harness (green on hardware)
     abi_conv_case(Geo{64, 16, 9, 9, 128, 3, 3, 1, 1, 1}, "up");      // ggp_kernel<2,2,2,128>, pre-split filter planes
@@ -433,6 +433,12 @@ int main(int argc, char** argv) {
     wgrad_case(Geo{32, 32, 9, 9, 192, 3, 3, 1, 1, 1}, false, 0.f, 1.f);    // 256 x 192 tile, two k tiles (288 rows), border taps
     if (!quick) wgrad_case(Geo{64, 29, 8, 8, 200, 3, 3, 1, 1, 1}, true, 1.f, 0.5f);    // 256 x 256 tile ragged in f, K = 261: bias row in the second k tile, two chunks per pixel
     if (!quick) wgrad_case(Geo{64, 16, 12, 12, 224, 5, 5, 2, 2, 2}, false, 0.f, 1.f);  // stride 2, 5 x 5, two chunks per pixel
+    if (!quick) wgrad_case(Geo{32, 32, 9, 9, 198, 3, 3, 1, 1, 1}, false, 0.f, 1.f);    // F % 4 != 0: the direct write-out
+  }
+  if (what == "wgwfin") {   // one block per tile (no slabs): scaleTargets / scaleOutput and the bias row in the kernel's own epilogue, both write-outs
+    setenv("CONVNET_EMU_WG_SPLITS", "1", 1);
+    wgrad_case(Geo{64, 29, 8, 8, 200, 3, 3, 1, 1, 1}, true, 1.f, 0.5f);
+    wgrad_case(Geo{32, 29, 8, 8, 198, 3, 3, 1, 1, 1}, true, 1.f, 0.5f);
   }
   if (what == "wgwvar" || all) {   // the staging loads spread over the chunk (wgrad tile 2)
     wgrad_case(Geo{32, 32, 9, 9, 192, 3, 3, 1, 1, 1}, false, 0.f, 1.f, 2);

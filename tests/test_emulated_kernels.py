@@ -76,6 +76,14 @@ def test_wide_wgrad_kernel_variant_in_emulation(emu_binary):
     assert r.returncode == 0 and lines[-1] == "ALL PASSED" and sum(l.startswith("PASS wgw(spread)") for l in lines) == 2, r.stdout + r.stderr
 
 
+def test_wide_wgrad_kernel_single_block_epilogue_in_emulation(emu_binary):
+    """one block per tile (forced: the launch policy splits the reduction at emulation sizes): scaleTargets, scaleOutput and the bias
+    row in the kernel's own epilogue, through the 16-byte write-out and through the direct one (F % 4 != 0)"""
+    r = subprocess.run([emu_binary, "wgwfin"], capture_output=True, text=True, timeout=1200)
+    lines = r.stdout.strip().splitlines()
+    assert r.returncode == 0 and lines[-1] == "ALL PASSED" and sum("splits=1 " in l and l.startswith("PASS wgw") for l in lines) == 2, r.stdout + r.stderr
+
+
 def test_wide_patch_kernel_tail_split_in_emulation(emu_binary):
     """11 tiles on an 8-slot "chip": the last round's three tiles are cut into three K-ranges (the kernel's tail-split branch, its raw
     partial tiles, gpw_tail_fix_kernel) — forced by the harness, the cost model never picks it at emulation sizes"""
