@@ -60,15 +60,13 @@ def _same_kernel(bench_name, prof_name):
             return n.split("::")[-1], []
         return n[:n.index("<")].split("::")[-1], n[n.index("<") + 1:n.rindex(">")].split(",")
     wb, wa = parse(bench_name)
-    # the opt-in wide kernels: "gpw_kernel<128x512,split,raw[,grouped|,ring2]>" is gpw_kernel<0 | 1 | 2> (its tail-fix kernel is "gpw_tail_fix_kernel");
-    # "wgw_kernel<256x192,split[,spread]>" / "<256x256,...>" are wgw_kernel<3, FV> / <4, FV>; "gpp_kernel<2,2,2,128,split,raw|planes>" is <2,2,2,128,BRAW>
+    # the wide kernels: "gpw_kernel<128x512,split,raw>" is chip::gpw_kernel (no template; its tail-fix kernel is "gpw_tail_fix_kernel");
+    # "wgw_kernel<256x192,split>" / "<256x256,split>" are wgw_kernel<3> / <4>; "gpp_kernel<2,2,2,128,split,raw|planes>" is <2,2,2,128,BRAW>
     flat = prof_name.replace(" ", "")
-    if wb == "gpw_kernel":   # gpw_kernel<VAR>: 0 plain, 1 "grouped", 2 "ring2"
-        var = "1" if "grouped" in wa else "2" if "ring2" in wa else "0"
-        return "gpw_kernel<%s>" % var in flat
+    if wb == "gpw_kernel":
+        return "gpw_kernel(" in flat or flat.endswith("gpw_kernel") or "gpw_kernel<" in flat
     if wb == "wgw_kernel":
-        fv = "1" if "spread" in wa else "0"   # wgw_kernel<NTL, FV>
-        return ("wgw_kernel<3,%s>" % fv in flat and "256x192" in wa) or ("wgw_kernel<4,%s>" % fv in flat and "256x256" in wa)
+        return ("wgw_kernel<3>" in flat and "256x192" in wa) or ("wgw_kernel<4>" in flat and "256x256" in wa)
     if wb == "gpp_kernel":
         return ("gpp_kernel<2,2,2,128,true>" in flat and "raw" in wa) or ("gpp_kernel<2,2,2,128,false>" in flat and "planes" in wa)
     fb, fa = parse(prof_name)

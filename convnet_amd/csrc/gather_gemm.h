@@ -247,7 +247,30 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
 // options (fin), or store the raw sums into this split's slab.  Shared by gg_kernel and gg_tail_fix_kernel.
 // reg_lo / reg_hi: the accumulator registers (of every row tile) this call writes out — all 16 from the GEMM kernels, a quarter from
 // each of the four blocks gg_tail_fix_kernel gives a tail tile.
-template <int WR, int WC, int MT, int CW, bool VEC>
+// acc_elem<true>: one accumulator element read out of ITS accumulation register by an explicit v_accvgpr_read.  gpw_kernel's 256
+// accumulators live in AGPRs; left to itself the compiler (ROCm 7.2) copies whole 16-register tuples into VGPRs for the write-out,
+// spills some of them, and its reload drops element 2 of a spilled tuple (found on the MI355X: one row of one row tile wrong in one
+// of four images whenever the split-K write-out ran — profiles/r05_wide_kernels.md).  Element by element there is nothing to spill.
+template <bool AGPR>
+__device__ __forceinline__ float acc_elem(float x) {
+#ifndef CONVNET_EMU
+  if constexpr (AGPR) {
+    float r;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(x));
+    return r;
+  }
+#endif
+  return x;
+}
+// in front of the first acc_elem<true>: the last MFMA's result registers are not readable for 18 cycles and the compiler's hazard
+// padding does not look into inline asm
+__device__ __forceinline__ void acc_settle() {
+#ifndef CONVNET_EMU
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#endif
+}
+
+template <int WR, int WC, int MT, int CW, bool VEC, bool ACC_AGPR = false>
 __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT][CW / 32], int row_tile, int col_tile, int split,
                                             int pncols, int pGX, int pG, int pdy0, int pdx0, int reg_lo = 0, int reg_hi = 16) {
   constexpr int NTC = CW / 32;
@@ -290,7 +313,7 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT]
       if (row >= p.R || reg < reg_lo || reg >= reg_hi) continue;
       fvec v;
 #pragma unroll
-      for (int u = 0; u < NTC; ++u) v[u] = acc[t][u][reg];
+      for (int u = 0; u < NTC; ++u) v[u] = acc_elem<ACC_AGPR>(acc[t][u][reg]);
       float* dp = base + (size_t)row * p.DP * N;
       if (fin) {
         const float bv = p.bias ? p.bias[row] : 0.f;
@@ -486,7 +509,7 @@ struct PatchBank {   // where the filter bank of the call comes from: forward fi
 // the bank as bf16 planes per row tile of TH rows (patch_gemm.hip: filter_planes_rt_kernel); out holds 96 * (KC/16) * TYX * ceil(R/TH)*TH bytes
 void filter_planes_rt_launch(const PatchBank& bank, void* out, int TYX, int TH, const char* op);
 void filter_planes_gk_launch(const float* W, void* out, int F, int K, int KP, int TH, const char* op);   // generic k order (conv1)
-bool patch_shape_ok(GGParams& p);
+bool patch_shape_ok(GGParams& p, size_t dst_elems);
 void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, const PatchBank& bank);
 
 // -------------------------------------------------------------------------------------------------

@@ -1911,7 +1911,7 @@ void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* tar
   if (vec && ggp_shape_ok(g.F, g.C) && gg_presplit_mode()) {
     // patch-resident gather on pre-split source planes (patch_gemm.hip) where the geometry has one
     p.KC = g.C;
-    if (patch_shape_ok(p)) {
+    if (patch_shape_ok(p, (size_t)g.N * p.DP * g.F)) {
       t_op = "conv_fprop";
       t_flops = 2.0 * g.N * p.G * (double)g.F * p.K;
       const PatchBank bank{filters->data_device, g.F, g.C, g.Ky, g.Kx, 0, 0, 1, 1, g.Ky, g.Kx, false};
@@ -2048,11 +2048,11 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
         GGParams p = base;
         p.K = k.K; p.GX = GX; p.G = GY * GX; p.TX = TXc; p.TYX = TYc * TXc;
         p.y0 = jy0; p.x0 = jx0; p.dy0 = iy0; p.dx0 = ix0;
-        if (patch_shape_ok(p)) {
+        const bool whole = g.sy == 1 && g.sx == 1 && GY == g.H && GX == g.W;
+        if (patch_shape_ok(p, whole ? (size_t)g.N * g.H * g.W * g.C : 0)) {
           const double cflops = 2.0 * g.N * p.G * (double)g.C * p.K;
           flops += cflops;
           t_flops = exec_total > 0 ? alg_flops * (cflops / exec_total) : 0.0;
-          const bool whole = g.sy == 1 && g.sx == 1 && GY == g.H && GX == g.W;
           const PatchBank bank{filters->data_device, g.F, g.C, g.Ky, g.Kx, cy, cx, g.sy, g.sx, TYc, TXc, true};
           patch_run(p, whole ? (size_t)g.N * g.H * g.W * g.C : 0, t_op, t_flops, bank);
           patched = true;

@@ -660,20 +660,17 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 2) void gpp_kernel(const GGParams
 // the image is a load of the zero page and a slot nobody reads a load into a dump region — every wave issues exactly 7 loads per
 // chunk and waits with a constant count in front of the chunk barrier.
 // Row tiles of 128 are exact for 384 and 256 rows; conv3/4 at 256 images are 254 tiles for 256 CUs.
-// NOT YET RUN ON HARDWARE (written at the end of round 4 with the GPU budget spent): opt-in only, patch mode 3.  Runs correctly in the
-// CPU emulation of this source (tests/test_emulated_kernels.py); its schedule against late-landing loads: tests/test_patch_wide_cpu.py.
-// VAR (patch modes 3 / 4 / 5, for the first A/B on hardware): 0 = one staging load per step, three-stage filter ring; 1 = the loads in
-// groups of three and four back to back; 2 = as 0 with the filter chunk staged ONE ahead into a TWO-stage ring (124 KB of LDS instead of
-// 136: nothing DMA-written above 128 KB, should M0 turn out narrower than the LDS).
-template <int VAR>
+// Patch mode 3, the default where its launch policy applies (patch_run).  First run on the MI355X in round 5 (parity green, conv4
+// 509 -> 452-475 us; profiles/r05_wide_kernels.md); the two variants written for that first A/B — staging loads in back-to-back groups, a
+// two-stage filter ring below 128 KB in case M0 were narrower than the LDS — measured the same to 1 % and are gone.  The CPU emulation
+// of this source (tests/test_emulated_kernels.py) and the schedule model (tests/test_patch_wide_cpu.py) stay as GPU-less checks.
 __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const GGClassTable ct) {
   constexpr int WC = 4, MT = 4, CW = 128, NTC = CW / 32, P = kWideP, NS = kWideNS;
   using fvec = __attribute__((ext_vector_type(NTC))) float;
   constexpr int NC = WC * 64;
   constexpr int ROWS = MT * 32;
   constexpr int A_STAGE = 6 * ROWS * 4;   // floats: 3 planes x 2 k-groups x ROWS x 16 bytes
-  constexpr bool GROUPED = VAR == 1;
-  constexpr int STA = VAR == 2 ? 2 : 3;   // A ring
+  constexpr int STA = 3;                  // A ring: filter chunks staged two ahead
   constexpr int SLAB = NS * 1024;         // floats per slab: a slot is 16 k-rows x 64 images of fp32
   static_assert(A_STAGE * 4 == WC * 3 * 1024, "three 1 KB pieces of a filter chunk per wave");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -809,7 +806,7 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
     const char* a_ptr = abase0 + a_chunk_bytes * (size_t)(cb_beg * TYX + (a_lo + r_beg) * TX + gb);   // wave-uniform
     // counters as plain integer arithmetic (0/1 flags, masks): booleans with && / ?: come back from the optimizer as branches
     int A_i = 0, A_r = r_beg, A_left = nchunks;   // tap slot, tap row - a_lo, chunks not yet issued
-    unsigned lds_f0 = lds_a, lds_f1 = lds_a + A_STAGE * 4u, lds_f2 = lds_a + 2u * A_STAGE * 4u;   // the ring stage to fill next first (STA == 2: f2 unused)
+    unsigned lds_f0 = lds_a, lds_f1 = lds_a + A_STAGE * 4u, lds_f2 = lds_a + 2u * A_STAGE * 4u;   // the ring stage to fill next first
     // (in two parts, so that a chunk can place them in different steps: the address into SGPRs, then the loads and the stepping)
     const char* a_cur = nullptr;
     unsigned a_lds = 0;
@@ -822,12 +819,8 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
     auto issue_a_step = [&]() __attribute__((always_inline)) {
       const unsigned f = lds_f0;
       lds_f0 = lds_f1;
-      if constexpr (STA == 3) {
-        lds_f1 = lds_f2;
-        lds_f2 = f;
-      } else {
-        lds_f1 = f;
-      }
+      lds_f1 = lds_f2;
+      lds_f2 = f;
       --A_left;
       const int more = (int)((unsigned)(-A_left) >> 31);   // 1 while chunks are left
       const int i1 = A_i + 1, w1 = (i1 * 11) >> 5;          // w1 = 1 when the tap row is complete (i1 == 3)
@@ -951,7 +944,7 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
       slab_next(1);
     }
     issue_a();
-    if constexpr (STA == 3) issue_a();   // (two ahead; the two-stage ring runs one ahead)
+    issue_a();   // (two ahead)
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
     __syncthreads();
 
@@ -1010,19 +1003,19 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
         // 0: which load the slot is, its addresses; column 1: the filter iterator) and the counters of the NEXT chunk (column 2).
         split_pair(u + 1, 0, fn);
         if (u == 0) issue_a_addr();
-        if (u == 1) { if constexpr (GROUPED) slot_go(); else slot_piece(K0{}); }
+        if (u == 1) slot_piece(K0{});
         mac_step(K0{}, fa, fc, u);
         split_pair(u + 1, 1, fn);
-        if (u == 0) { if constexpr (GROUPED) issue_a_go(); else issue_a_piece(K0{}); }
-        if (u == 1 && !GROUPED) slot_piece(K1{});
+        if (u == 0) issue_a_piece(K0{});
+        if (u == 1) slot_piece(K1{});
         mac_step(K1{}, fa, fc, u);
         split_pair(u + 1, 2, fn);
-        if (u == 0 && !GROUPED) issue_a_piece(K1{});
-        if (u == 1 && !GROUPED) slot_piece(K2{});
+        if (u == 0) issue_a_piece(K1{});
+        if (u == 1) slot_piece(K2{});
         mac_step(K2{}, fa, fc, u);
         split_pair(u + 1, 3, fn);
-        if (u == 0 && !GROUPED) issue_a_piece(K2{});
-        if (u == 1 && !GROUPED) slot_piece(K3{});
+        if (u == 0) issue_a_piece(K2{});
+        if (u == 1) slot_piece(K3{});
         mac_step(K3{}, fa, fc, u);
         if (u == 0) next_slot_kind();
         if (u == 1) issue_a_step();
@@ -1034,9 +1027,8 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
       // the last column's split is complete HERE (the compiler otherwise sinks it towards its use, out of the MFMA shadow)
       CHIP_PIN_SPLIT8(fb[(NTC - 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
-      // everything this wave issued before this chunk's batch has landed: vmcnt(7) lgkmcnt(0) — with the two-stage ring this chunk's three
-      // filter loads too (they are the first of the seven): vmcnt(4)
-      __builtin_amdgcn_s_waitcnt(STA == 3 ? 0x0077 : 0x0074);
+      // everything this wave issued before this chunk's batch has landed: vmcnt(7) lgkmcnt(0)
+      __builtin_amdgcn_s_waitcnt(0x0077);
       __syncthreads();                      // ... and every other wave's; every wave has read this chunk's A and slab slots out of LDS
       {
         const Split8& fc = fb[(NTC - 1) & 1];
@@ -1076,7 +1068,8 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
     __builtin_amdgcn_s_waitcnt(0x0070);   // the last two batches (dump / free-stage loads) before the LDS is released
   }
 
-  // ---- epilogue: gg_kernel's, with the unit column mapping (GGParams::patch) -------------------------------------------------
+  // ---- epilogue: gg_kernel's, with the unit column mapping (GGParams::patch); every accumulator read straight out of its AGPR
+  acc_settle();
   if (tsplit >= 0) {
     float* pp = p.tail_partial + ((size_t)(L - p.tail_first) * p.tail_splits + tsplit) * (size_t)(ROWS * WC * CW);
 #pragma unroll
@@ -1085,12 +1078,12 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
       for (int reg = 0; reg < 16; ++reg) {
         fvec v;
 #pragma unroll
-        for (int u = 0; u < NTC; ++u) v[u] = acc[t][u][reg];
+        for (int u = 0; u < NTC; ++u) v[u] = acc_elem<true>(acc[t][u][reg]);
         *reinterpret_cast<fvec*>(pp + ((size_t)(t * 16 + reg) * NC + tid) * NTC) = v;
       }
     return;
   }
-  gg_epilogue<1, WC, MT, CW, true>(p, acc, row_tile, col_tile, split, T.ncols, T.GX, T.G, T.dy0, T.dx0);
+  gg_epilogue<1, WC, MT, CW, true, true>(p, acc, row_tile, col_tile, split, T.ncols, T.GX, T.G, T.dy0, T.dx0);
 }
 
 // gg_tail_fix_kernel for gpw_kernel's tile: the same four blocks per tail tile, each summing the tail_splits partial tiles of a quarter
@@ -1131,7 +1124,7 @@ namespace {
 
 int g_patch_mode = -1;
 inline int patch_mode() {
-  if (g_patch_mode < 0) g_patch_mode = CHIP_KNOB("CONVNET_GG_PATCH", 0);
+  if (g_patch_mode < 0) g_patch_mode = CHIP_KNOB("CONVNET_GG_PATCH", 3);
   return g_patch_mode;
 }
 
@@ -1146,12 +1139,55 @@ int patch_slots(Kern kern, int threads, size_t lds) {
   return (n < 1 ? 1 : n) * 256;
 }
 
+// gpw_kernel's split-K by wave quantisation (gg_launch_cfg's rule; the unit of a K-range is the superchunk) and its LAUNCH POLICY.
+// A 128 x 512 tile with 512-register waves owns its CU, so a launch is rounds of `slots` blocks and nothing fills a partial one.
+// Measured on the MI355X (profiles/r05_wide_kernels.md): one round that fills the chip beats ggp_kernel by 7-12 % (conv3 fprop, conv4,
+// conv5 with and without two K-ranges), a K-split over TWO rounds loses to ggp_kernel's tail split (conv3 dgrad: 170 tiles, 3 ranges,
+// 435 + 37 us against 343 + 23) — every extra round pays the 256 KB write-out and the prologue again.  So: take the launch when the
+// blocks fill >= 85 % of their rounds and either nothing is split or everything runs in one round; otherwise the caller's ggp_kernel.
+struct WidePlan {
+  int splits;
+  bool take;
+};
+inline WidePlan wide_plan(const GGParams& p, size_t dst_elems, int slots) {
+  const int CB = p.KC / BK, TYn = p.TYX / p.TX;
+  const int tiles = divup(p.R, 128) * divup((p.N / 64) * p.G, kWideP);
+  const int nsc = CB * TYn, kchunks = CB * p.TYX;
+  const double block_rate = 230e12 / slots;
+  const double fl = 2.0 * 128 * (double)(kWideP * 64) * (double)p.K;
+  int splits = 1;
+  if (dst_elems > 0 && kchunks >= 16) {
+    double best_t = 1e30;
+    for (int sp = 1; sp <= 16 && kchunks / sp >= 8 && nsc / sp >= 1; ++sp) {
+      const double rounds = std::ceil(tiles * (double)sp / slots);
+      double t = rounds * (fl / sp) / block_rate;
+      if (sp > 1) t += sizeof(float) * (double)dst_elems * (2.0 * sp + 1) / 4.0e12 + 4e-6;
+      if (t < best_t * 0.97) {
+        best_t = t;
+        splits = sp;
+      }
+    }
+  }
+  const int cps = divup(nsc, splits);
+  splits = divup(nsc, cps);
+  const long long blocks = (long long)tiles * splits;
+  const long long rounds = (blocks + slots - 1) / slots;
+  const bool fill = (double)blocks >= 0.85 * (double)(rounds * slots) || (splits == 1 && rounds >= 4);   // (many rounds: the tail split evens the last)
+  return {splits, fill && (splits == 1 || rounds == 1)};
+}
+constexpr size_t kWideLds = sizeof(float) * (3 * (6 * 128 * 4) + 2 * (kWideNS * 1024) + 1024);   // filter ring + two slabs + the dump slot
+inline int wide_slots() {
+  static const int n = patch_slots(gpw_kernel, 256, kWideLds);
+  return n;
+}
+
 }  // namespace
 
 // Can this gather (GGParams filled by conv_up_impl / conv_down_impl for ggp_kernel's tap-major pre-split path: KC > 0, apre) run on
 // gpp_kernel / gpw_kernel?  Fills the tap groups.  A tap row is cut into ssx groups of taps that are ssx apart (one group for a
 // stride-1 gather): inside a group neighbouring pixels' taps coincide, slot i of pixel j+1 = slot i+1 of pixel j.
-bool patch_shape_ok(GGParams& p) {
+// dst_elems: the size of the whole destination when the launch may be cut in K (0: it may not).
+bool patch_shape_ok(GGParams& p, size_t dst_elems) {
   if (!patch_mode() || matrix_path() == 0 || p.KC <= 0 || p.KC % BK != 0) return false;
   if (p.N % 64 != 0 || p.GX < 4 || p.R <= 64) return false;
   if ((size_t)p.SH * p.SW * p.N >= (size_t(1) << 28)) return false;   // the raw build's lane offset spans 3 channel planes in 32 bits
@@ -1165,7 +1201,10 @@ bool patch_shape_ok(GGParams& p) {
   }
   if (p.ng == 1) { p.gcnt[1] = p.gcnt[0]; p.gb0[1] = p.gb0[0]; }
   // gpw_kernel: 3-tap rows of a stride-1 gather; its 12 slots hold ONE wrap per tile: output rows of >= 8 pixels
-  if (patch_mode() >= 3 && (p.ng != 1 || p.gcnt[0] != 3 || p.GX < kWideP)) return false;
+  if (patch_mode() >= 3) {
+    if (p.ng != 1 || p.gcnt[0] != 3 || p.GX < kWideP) return false;
+    return patch_mode() == 4 || wide_plan(p, dst_elems, wide_slots()).take;   // (mode 4: the parity tests' small shapes, A/B runs)
+  }
   return true;
 }
 
@@ -1176,7 +1215,7 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
   constexpr int ROWS = 128;                         // both kernels
   static_assert(ROWS == WR * MT * 32, "row tile");
   // CONVNET_GG_PATCH / convnet_hip_set_patch_mode: 1 = gpp_kernel on a raw fp32 slab, split by the consumers; 2 = gpp_kernel on bf16
-  // planes of the source tensor (one more pass); 3 / 4 / 5 = gpw_kernel (8 units x 128 rows, raw slab, no producer wave) and its two variants
+  // planes of the source tensor (one more pass); 3 = gpw_kernel (8 units x 128 rows, raw slab, no producer wave) where wide_plan takes the launch, 4 = wherever the shape allows
   const int mode = patch_mode();
   const bool wide = mode >= 3, braw = mode != 2;
   const int PU = wide ? kWideP : kPatchP;           // units per tile
@@ -1212,14 +1251,10 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
   p.zero = zero_page();
   p.prio = CHIP_DIAG_KNOB("CONVNET_GPP_DIAG", 0);
   constexpr size_t lds_p = sizeof(float) * (3 * (6 * ROWS * 4) + 2 * (6 * 8 * 256)), lds_r = sizeof(float) * (3 * (6 * ROWS * 4) + 2 * (4 * 8 * 256));
-  constexpr size_t lds_w3 = sizeof(float) * (3 * (6 * ROWS * 4) + 2 * (kWideNS * 1024) + 1024);   // + the dump slot
-  constexpr size_t lds_w2 = lds_w3 - sizeof(float) * (6 * ROWS * 4);                               // two-stage filter ring (mode 5)
-  const size_t lds_w = mode == 5 ? lds_w2 : lds_w3;
+  constexpr size_t lds_w = kWideLds;
   static const int slots_p = patch_slots(gpp_kernel<WR, WC, MT, CW, false>, WR * WC * 64 + 64, lds_p);
   static const int slots_r = patch_slots(gpp_kernel<WR, WC, MT, CW, true>, WR * WC * 64 + 64, lds_r);
-  static const int slots_w0 = patch_slots(gpw_kernel<0>, 256, lds_w3), slots_w1 = patch_slots(gpw_kernel<1>, 256, lds_w3), slots_w2 = patch_slots(gpw_kernel<2>, 256, lds_w2);
-  const int slots_w = mode == 5 ? slots_w2 : mode == 4 ? slots_w1 : slots_w0;
-  const int slots = wide ? slots_w : braw ? slots_r : slots_p;
+  const int slots = wide ? wide_slots() : braw ? slots_r : slots_p;
   const int tiles = p.row_tiles * p.col_tiles;
   const int TYn = p.TYX / p.TX;
   const int nsc = CB * TYn * p.ng;                    // superchunks of a whole reduction
@@ -1227,7 +1262,9 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
   const double block_rate = 230e12 / slots;
   // split-K by wave quantisation, as gg_launch_cfg; the unit of a K-range is the superchunk
   int splits = 1;
-  if (dst_elems > 0 && kchunks >= 16) {
+  if (wide) {
+    splits = wide_plan(p, dst_elems, slots).splits;
+  } else if (dst_elems > 0 && kchunks >= 16) {
     const double fl = 2.0 * ROWS * (double)TCOLS * (double)p.K;
     double best_t = 1e30;
     for (int sp = 1; sp <= 16 && kchunks / sp >= 8 && nsc / sp >= 1; ++sp) {
@@ -1276,10 +1313,8 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
   static const GGClassTable kNone = {};
   {
     // (",split" in a timer name is how bench.py prices the kernel on the bf16 pipe: kernel_peak)
-    KernelTimer timer(mode == 5 ? "gpw_kernel<128x512,split,raw,ring2>" : mode == 4 ? "gpw_kernel<128x512,split,raw,grouped>" : wide ? "gpw_kernel<128x512,split,raw>" : braw ? "gpp_kernel<2,2,2,128,split,raw>" : "gpp_kernel<2,2,2,128,split,planes>", op, flops, 0.0, 0.0);
-    if (mode == 5) hipLaunchKernelGGL(gpw_kernel<2>, grid, dim3(threads), lds_w, stream(), p, kNone);
-    else if (mode == 4) hipLaunchKernelGGL(gpw_kernel<1>, grid, dim3(threads), lds_w, stream(), p, kNone);
-    else if (wide) hipLaunchKernelGGL(gpw_kernel<0>, grid, dim3(threads), lds_w, stream(), p, kNone);
+    KernelTimer timer(wide ? "gpw_kernel<128x512,split,raw>" : braw ? "gpp_kernel<2,2,2,128,split,raw>" : "gpp_kernel<2,2,2,128,split,planes>", op, flops, 0.0, 0.0);
+    if (wide) hipLaunchKernelGGL(gpw_kernel, grid, dim3(threads), lds_w, stream(), p, kNone);
     else if (braw) hipLaunchKernelGGL((gpp_kernel<WR, WC, MT, CW, true>), grid, dim3(threads), lds_r, stream(), p, kNone);
     else hipLaunchKernelGGL((gpp_kernel<WR, WC, MT, CW, false>), grid, dim3(threads), lds_p, stream(), p, kNone);
   }
@@ -1295,6 +1330,6 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
 }  // namespace chip
 
 extern "C" {
-void convnet_hip_set_patch_mode(int mode) { chip::g_patch_mode = mode < 0 ? 0 : mode > 5 ? 5 : mode; }
+void convnet_hip_set_patch_mode(int mode) { chip::g_patch_mode = mode < 0 ? 0 : mode > 4 ? 4 : mode; }
 int convnet_hip_get_patch_mode(void) { return chip::patch_mode(); }
 }

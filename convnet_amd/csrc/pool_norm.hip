@@ -625,6 +625,7 @@ inline int fixed_window(const PoolGeo& g, bool vec) {
 inline dim3 pool_xcd_grid(PoolGeo& g, int xblocks, int rows, dim3 plain) {
   const bool off = CHIP_DIAG_KNOB("CONVNET_POOL_NO_XCD", 0) != 0;
   const long long total = (long long)xblocks * rows * g.C;
+  g.xper = g.xtotal = g.xrows = g.xbx = 0;   // a second call on the same geometry (the 2 x 2-block undo) starts clean
   if (off || total < 64 || total > (1ll << 30)) return plain;
   g.xbx = xblocks; g.xrows = rows; g.xtotal = (int)total; g.xper = (int)((total + 7) / 8);
   return dim3(8 * g.xper);

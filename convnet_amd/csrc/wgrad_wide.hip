@@ -25,9 +25,9 @@
 
 namespace chip {
 
-template <int NTL, int FV>
+template <int NTL>
 __global__ __launch_bounds__(256, 1) void wgw_kernel(const WGParams p) {
-  using S = wgw::Schedule<NTL, FV>;
+  using S = wgw::Schedule<NTL>;
   constexpr int WN = 2, MT = 4, NT = 256;
   constexpr int KT = 256, FT = WN * NTL * 32;
   constexpr int A_STAGE = KT * WG_NB, B_STAGE = FT * WG_NB;   // floats: rows of 32 images
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void wgw_kernel(const WGParams p) {
       f.l[q] = pk_bf16(s0, s1);
     };
     auto do_unit = [&](auto GG, auto II) __attribute__((always_inline)) {
-      constexpr wgw::Unit x = wgw::kSchedule<NTL, FV>.u[decltype(GG)::value][decltype(II)::value];
+      constexpr wgw::Unit x = wgw::kSchedule<NTL>.u[decltype(GG)::value][decltype(II)::value];
       if constexpr (x.kind == wgw::kReadB) {
         constexpr int col = x.a % COLS, h = col / NTL, u = col % NTL;
         const float* rowp = (x.a == COLS ? b_nxt : b_cur) + u * 32 * WG_NB;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void wgw_kernel(const WGParams p) {
           __syncthreads();
         }
         __builtin_amdgcn_sched_barrier(0);
-        static_for<0, wgw::kSchedule<NTL, FV>.n[g]>([&](auto I) __attribute__((always_inline)) { do_unit(GG, I); });
+        static_for<0, wgw::kSchedule<NTL>.n[g]>([&](auto I) __attribute__((always_inline)) { do_unit(GG, I); });
         const Split8& b = fb[j % NSLOT];
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
@@ -320,17 +320,17 @@ namespace {
 
 int g_wgrad_tile = -1;
 inline int wgrad_tile() {
-  if (g_wgrad_tile < 0) g_wgrad_tile = CHIP_KNOB("CONVNET_WG_TILE", 0);
+  if (g_wgrad_tile < 0) g_wgrad_tile = CHIP_KNOB("CONVNET_WG_TILE", 1);
   return g_wgrad_tile;
 }
 
-template <int NTL, int FV>
+template <int NTL>
 void wgw_launch(WGParams& p, const char* op, double flops, double exec) {
   constexpr int KT = 256, FT = 64 * NTL;
   const size_t lds = sizeof(float) * 2 * (KT + FT) * WG_NB;
   static bool once = false;
   if (!once) {
-    CHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgw_kernel<NTL, FV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgw_kernel<NTL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     once = true;
   }
   p.k_tiles = divup(p.K, KT);
@@ -361,9 +361,9 @@ void wgw_launch(WGParams& p, const char* op, double flops, double exec) {
   p.partial = splits > 1 ? static_cast<float*>(workspace(sizeof(float) * total * (splits + (groups > 1 ? groups : 0)))) : nullptr;
   dim3 grid(((tiles * splits + 7) / 8) * 8), block(256);
   {
-    KernelTimer timer(NTL == 4 ? (FV ? "wgw_kernel<256x256,split,spread>" : "wgw_kernel<256x256,split>") : (FV ? "wgw_kernel<256x192,split,spread>" : "wgw_kernel<256x192,split>"),
+    KernelTimer timer(NTL == 4 ? "wgw_kernel<256x256,split>" : "wgw_kernel<256x192,split>",
                       op, flops, 0.0, exec);
-    hipLaunchKernelGGL((wgw_kernel<NTL, FV>), grid, block, lds, stream(), p);
+    hipLaunchKernelGGL((wgw_kernel<NTL>), grid, block, lds, stream(), p);
   }
   if (splits > 1) wg_reduce_launch(p, total, splits, groups, op);
 }
@@ -378,15 +378,14 @@ bool wgw_try(WGParams& p, bool vec, bool split_products, const char* op, double 
   if (p.N % WG_NB != 0 || p.K < 256 || p.F < 192) return false;
   if (p.chunks_total < 64) return false;   // an FC weight gradient: a handful of chunks per 256 x 256 outputs, write-out-bound either way
   const int pad256 = divup(p.F, 256) * 256, pad192 = divup(p.F, 192) * 192;
-  const bool spread = wgrad_tile() == 2;   // (fetch variant 1: wgrad_wide_schedule.h)
-  if (pad192 < pad256) spread ? wgw_launch<3, 1>(p, op, flops, exec) : wgw_launch<3, 0>(p, op, flops, exec);
-  else spread ? wgw_launch<4, 1>(p, op, flops, exec) : wgw_launch<4, 0>(p, op, flops, exec);
+  if (pad192 < pad256) wgw_launch<3>(p, op, flops, exec);
+  else wgw_launch<4>(p, op, flops, exec);
   return true;
 }
 
 }  // namespace chip
 
 extern "C" {
-void convnet_hip_set_wgrad_tile(int mode) { chip::g_wgrad_tile = mode < 0 ? 0 : mode > 2 ? 2 : mode; }
+void convnet_hip_set_wgrad_tile(int mode) { chip::g_wgrad_tile = mode < 0 ? 0 : mode > 1 ? 1 : mode; }
 int convnet_hip_get_wgrad_tile(void) { return chip::wgrad_tile(); }
 }

@@ -14,10 +14,9 @@ struct Unit {
 };
 constexpr int kMaxUnits = 5;
 
-// FV (fetch variant, for the first A/B on hardware): 0 = the staging loads in the first sub-steps of the chunk, one each (the most time to
-// land, but the first half of the chunk then carries 6 other instructions per MFMA gap); 1 = spread evenly over everything in front of
-// the last step before the barrier.
-template <int NTL, int FV = 0>
+// (A variant with the staging loads spread evenly over the chunk instead of issued in its first sub-steps was written for the first
+// A/B on hardware and measured the same to 0.3 % — conv2 weight gradients 955 vs 958 us, profiles/r05_wide_kernels.md; gone.)
+template <int NTL>
 struct Schedule {
   static constexpr int COLS = 2 * NTL, G = 6 * COLS, NSLOT = NTL == 4 ? 4 : 3, GB = 6 * (COLS - 2);   // barrier in front of sub-step GB
   static constexpr int NA = 8, NB = 2 * NTL, NF = NA + NB;
@@ -29,7 +28,7 @@ struct Schedule {
     add(0, Unit{kWalkBegin, 0, 0, 0});
     int last = 0;
     for (int i = 0; i < NF; ++i) {
-      last = FV == 0 ? i : (i * (GB - 6)) / NF;
+      last = i;
       add(last, Unit{kFetch, i, 0, 0});
     }
     add(last + 1, Unit{kWalkStep, 0, 0, 0});
@@ -87,9 +86,9 @@ struct Schedule {
 };
 
 // The rules the kernel relies on, checked at compile time.
-template <int NTL, int FV = 0>
+template <int NTL>
 constexpr bool schedule_ok() {
-  using S = Schedule<NTL, FV>;
+  using S = Schedule<NTL>;
   constexpr S s{};
   int readB[S::COLS + 1] = {}, readA[2][4] = {}, pairB[S::COLS + 1][4] = {}, pairA[2][4][4] = {}, fetch[S::NF] = {};
   for (int j = 0; j <= S::COLS; ++j) {
@@ -140,7 +139,7 @@ constexpr bool schedule_ok() {
   }
   if (walk_begin != 0 || walk_step < 0) return false;
   for (int i = 0; i < S::NF; ++i)
-    if (fetch[i] < 0 || fetch[i] >= (FV == 0 ? 6 * NTL : S::GB - 6)) return false;   // staged early: at least the last step in front of the barrier is their time to land
+    if (fetch[i] < 0 || fetch[i] >= 6 * NTL) return false;   // staged early: at least the last step in front of the barrier is their time to land
   for (int j = 1; j <= S::COLS; ++j) {
     for (int q = 0; q < 4; ++q) {
       if (pairB[j][q] < 0) return false;
@@ -160,9 +159,9 @@ constexpr bool schedule_ok() {
     if (readA[1][t] >= S::GB || readA[0][t] < S::GB) return false;
   return true;
 }
-static_assert(schedule_ok<3>() && schedule_ok<4>() && schedule_ok<3, 1>() && schedule_ok<4, 1>(), "wgw_kernel: schedule breaks a rule");
-template <int NTL, int FV>
-inline constexpr Schedule<NTL, FV> kSchedule{};
+static_assert(schedule_ok<3>() && schedule_ok<4>(), "wgw_kernel: schedule breaks a rule");
+template <int NTL>
+inline constexpr Schedule<NTL> kSchedule{};
 
 }  // namespace wgw
 }  // namespace chip

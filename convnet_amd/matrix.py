@@ -57,8 +57,13 @@ class Matrix:
         Matrix.UseCurrentStream()
         # The library's default at the C ABI is the IEEE fp32 matrix instruction (path 0); this host — trainer, tests, bench —
         # selects the bf16-split products (include/convnet_hip.h: convnet_hip_set_matrix_path) unless the environment already chose.
-        if not os.environ.get("CONVNET_GG_SPLIT"):
+        # Once per process: a later SetupCUDADevice (a second net, a test suite's re-init) must not undo a path the host has chosen
+        # explicitly through the library in between.
+        if not os.environ.get("CONVNET_GG_SPLIT") and not Matrix._path_chosen:
             lib.convnet_hip_set_matrix_path(1)
+        Matrix._path_chosen = True
+
+    _path_chosen = False
 
     _shared_streams = {}
 

@@ -114,20 +114,19 @@ int convnet_hip_get_matrix_path(void);
  *   1: gpp_kernel, raw  — 4 neighbouring pixels x 64 images per block; the source pixels of a whole tap row staged once, as fp32;
  *   2: gpp_kernel, planes — the same tile reading the source from bf16 planes written by one extra pass (act_planes_kernel);
  *   3: gpw_kernel — 8 neighbouring pixels x 64 images x 128 rows per block, raw fp32 source, the block's four waves stage for
- *      themselves (3x3 stride-1 gathers with output rows >= 8 pixels; other shapes fall back to mode 0).  EXPERIMENTAL: written after
- *      the last hardware run of its round; runs correctly in a CPU emulation of its source (tests/test_emulated_kernels.py).
- *   4, 5: variants of 3 for the first A/B on hardware (4: its staging loads in groups instead of one per step; 5: a two-stage filter
- *      ring, 124 KB of LDS).
- * Initial value: environment CONVNET_GG_PATCH, else 0. */
+ *      themselves: 3x3 stride-1 gathers with output rows >= 8 pixels whose blocks fill their rounds on the chip (its launch policy,
+ *      patch_gemm.hip: wide_plan); every other shape runs as in mode 0.  The default since round 5 (first run on the MI355X there:
+ *      parity green, conv3 fprop / conv4 / conv5 7-12 % faster than mode 0).
+ *   4: as 3 without the launch policy — gpw_kernel wherever the shape allows (the parity tests' small geometries, A/B runs).
+ * Initial value: environment CONVNET_GG_PATCH, else 3. */
 void convnet_hip_set_patch_mode(int mode);
 int convnet_hip_get_patch_mode(void);
 /* Which kernel runs the weight gradients (conv wgrad, FC wgrad) on matrix path 1 — a schedule choice like the one above:
  *   0: wg_kernel — 128 x 128 tile, four waves of 64 x 64, two blocks per CU;
- *   1: wgw_kernel — 256 x 256 (or 256 x 192) tile, four waves of 128 x 128, one block per CU (N % 32 == 0, K >= 256, F >= 192; other
- *      shapes stay on wg_kernel).  EXPERIMENTAL: written after the last hardware run of its round; runs correctly in a CPU emulation of its
- *      source (tests/test_emulated_kernels.py), its schedule is checked at compile time.
- *   2: as 1 with the staging loads of a chunk spread over the chunk instead of issued at its start (variant for the first A/B on hardware).
- * Initial value: environment CONVNET_WG_TILE, else 0. */
+ *   1: wgw_kernel — 256 x 256 (or 256 x 192) tile, four waves of 128 x 128, one block per CU: conv weight gradients with N % 32 == 0,
+ *      K >= 256, F >= 192 and >= 64 chunks of reduction; other shapes (conv1, the FC layers) stay on wg_kernel.  The default since
+ *      round 5 (first run on the MI355X there: parity green, conv2-5 weight gradients 24-29 % faster).
+ * Initial value: environment CONVNET_WG_TILE, else 1. */
 void convnet_hip_set_wgrad_tile(int mode);
 int convnet_hip_get_wgrad_tile(void);
 const char* get_last_cuda_error(void);               /* cudamat.cuh:109 */

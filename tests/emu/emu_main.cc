@@ -102,7 +102,7 @@ static void fprop_case(const Geo& g, int mode, const char* tag) {
   p.DW = Mx; p.DP = My * Mx; p.dsy = 1; p.dsx = 1; p.dy0 = 0; p.dx0 = 0;
   p.scaleTargets = 0.f; p.relu = 0;
   p.KC = g.C;
-  const bool ok = patch_shape_ok(p);
+  const bool ok = patch_shape_ok(p, (size_t)g.N * p.DP * g.F);
   if (ok) {
     const PatchBank bank{w, g.F, g.C, g.Ky, g.Kx, 0, 0, 1, 1, g.Ky, g.Kx, false};
     patch_run(p, (size_t)g.N * p.DP * g.F, "conv_fprop", 0.0, bank);
@@ -143,7 +143,7 @@ static void dgrad_case(const Geo& g, int mode, const char* tag) {
   p.KC = g.F; p.apre = 1;
   p.K = g.F * TYX; p.GX = g.W; p.G = g.H * g.W; p.TX = g.Kx; p.TYX = TYX;
   p.y0 = g.pad; p.x0 = g.pad; p.dy0 = 0; p.dx0 = 0;
-  const bool ok = patch_shape_ok(p);
+  const bool ok = patch_shape_ok(p, (size_t)g.N * g.H * g.W * g.C);
   if (ok) {
     const PatchBank bank{w, g.F, g.C, g.Ky, g.Kx, 0, 0, 1, 1, g.Ky, g.Kx, true};
     patch_run(p, (size_t)g.N * g.H * g.W * g.C, "conv_dgrad", 0.0, bank);
@@ -190,7 +190,7 @@ static void wgrad_case(const Geo& g, bool with_bias, float scaleTargets, float s
   const bool ok = wgw_try(p, true, true, "conv_wgrad", 0.0, 0.0);
   double err = ok ? rel_err(dw, ref) : 1.0;
   if (ok && with_bias && p.bias_dst) err = std::max(err, rel_err(db, refb));
-  verdict(std::string(tile_mode == 2 ? "wgw(spread)" : "wgw") + " wgrad N" + std::to_string(g.N) + " C" + std::to_string(g.C) + " " + std::to_string(g.H) + "x" + std::to_string(g.W) + " F" + std::to_string(g.F) +
+  verdict(std::string("wgw") + " wgrad N" + std::to_string(g.N) + " C" + std::to_string(g.C) + " " + std::to_string(g.H) + "x" + std::to_string(g.W) + " F" + std::to_string(g.F) +
               " k" + std::to_string(g.Ky) + " s" + std::to_string(g.sy) + " p" + std::to_string(g.pad) + (with_bias ? (p.bias_dst ? " +bias row" : " (no spare row for the bias)") : "") +
               " splits=" + std::to_string(p.splits),
           err, ok);
@@ -411,23 +411,16 @@ int main(int argc, char** argv) {
     if (!quick) dgrad_case(Geo{64, 96, 6, 6, 16, 3, 3, 1, 1, 1}, 1, "gpp(raw)");
   }
   if (what == "gpw" || all || quick) {
-    fprop_case(Geo{64, 16, 9, 9, 96, 3, 3, 1, 1, 1}, 3, "gpw");     // 9-wide rows: a wrap in almost every tile, ragged last tile
-    if (!quick) fprop_case(Geo{128, 32, 8, 8, 130, 3, 3, 1, 1, 1}, 3, "gpw");   // two image blocks, two channel blocks (split-K), partial second row tile
-    if (!quick) fprop_case(Geo{64, 16, 10, 10, 72, 3, 3, 1, 1, 0}, 3, "gpw");   // pad 0: 8-wide output rows
-    dgrad_case(Geo{64, 96, 9, 9, 16, 3, 3, 1, 1, 1}, 3, "gpw");
-    if (!quick) dgrad_case(Geo{64, 72, 10, 10, 32, 3, 3, 1, 1, 0}, 3, "gpw");   // conv5 type: 8 x 8 derivatives into 10 x 10
-  }
-  if (what == "gpwvar" || all) {   // its two variants: grouped staging loads (mode 4), two-stage filter ring (mode 5)
-    fprop_case(Geo{64, 16, 9, 9, 96, 3, 3, 1, 1, 1}, 4, "gpw(grouped)");
-    dgrad_case(Geo{64, 96, 9, 9, 16, 3, 3, 1, 1, 1}, 4, "gpw(grouped)");
-    fprop_case(Geo{64, 16, 9, 9, 96, 3, 3, 1, 1, 1}, 5, "gpw(ring2)");
-    fprop_case(Geo{128, 32, 8, 8, 130, 3, 3, 1, 1, 1}, 5, "gpw(ring2)");
-    dgrad_case(Geo{64, 96, 9, 9, 16, 3, 3, 1, 1, 1}, 5, "gpw(ring2)");
+    fprop_case(Geo{64, 16, 9, 9, 96, 3, 3, 1, 1, 1}, 4, "gpw");     // 9-wide rows: a wrap in almost every tile, ragged last tile
+    if (!quick) fprop_case(Geo{128, 32, 8, 8, 130, 3, 3, 1, 1, 1}, 4, "gpw");   // two image blocks, two channel blocks (split-K), partial second row tile
+    if (!quick) fprop_case(Geo{64, 16, 10, 10, 72, 3, 3, 1, 1, 0}, 4, "gpw");   // pad 0: 8-wide output rows
+    dgrad_case(Geo{64, 96, 9, 9, 16, 3, 3, 1, 1, 1}, 4, "gpw");
+    if (!quick) dgrad_case(Geo{64, 72, 10, 10, 32, 3, 3, 1, 1, 0}, 4, "gpw");   // conv5 type: 8 x 8 derivatives into 10 x 10
   }
   if (what == "gpwtail") {   // 11 tiles on an 8-slot "chip", the last round's 3 tiles cut in 3 K-ranges: tail split + gpw_tail_fix_kernel
     setenv("CONVNET_EMU_SLOTS", "8", 1);   // (read once, at the first patch_run of the mode: run this leg in its own process)
     setenv("CONVNET_EMU_TAIL", "3", 1);
-    fprop_case(Geo{64, 64, 9, 9, 96, 3, 3, 1, 1, 1}, 3, "gpw(tail split)");
+    fprop_case(Geo{64, 64, 9, 9, 96, 3, 3, 1, 1, 1}, 4, "gpw(tail split)");
   }
   if (what == "wgw" || all || quick) {
     wgrad_case(Geo{32, 32, 9, 9, 192, 3, 3, 1, 1, 1}, false, 0.f, 1.f);    // 256 x 192 tile, two k tiles (288 rows), border taps
@@ -439,10 +432,6 @@ int main(int argc, char** argv) {
     setenv("CONVNET_EMU_WG_SPLITS", "1", 1);
     wgrad_case(Geo{64, 29, 8, 8, 200, 3, 3, 1, 1, 1}, true, 1.f, 0.5f);
     wgrad_case(Geo{32, 29, 8, 8, 198, 3, 3, 1, 1, 1}, true, 1.f, 0.5f);
-  }
-  if (what == "wgwvar" || all) {   // the staging loads spread over the chunk (wgrad tile 2)
-    wgrad_case(Geo{32, 32, 9, 9, 192, 3, 3, 1, 1, 1}, false, 0.f, 1.f, 2);
-    wgrad_case(Geo{64, 29, 8, 8, 200, 3, 3, 1, 1, 1}, true, 1.f, 0.5f, 2);
   }
   std::printf("%s\n", g_fail ? "SOME FAILED" : "ALL PASSED");
   return g_fail ? 1 : 0;

@@ -62,20 +62,6 @@ def test_wide_kernels_run_correctly_in_emulation(emu_binary):
     assert any(l.startswith("PASS gpw dgrad") for l in lines) and any(l.startswith("PASS wgw wgrad") for l in lines)
 
 
-@pytest.mark.skipif(not os.environ.get("CONVNET_EMU_ALL"), reason="the variants of gpw_kernel: CONVNET_EMU_ALL=1 (~40 s)")
-def test_wide_patch_kernel_variants_in_emulation(emu_binary):
-    r = subprocess.run([emu_binary, "gpwvar"], capture_output=True, text=True, timeout=1200)
-    lines = r.stdout.strip().splitlines()
-    assert r.returncode == 0 and lines[-1] == "ALL PASSED" and sum(l.startswith("PASS gpw(ring2)") for l in lines) == 3, r.stdout + r.stderr
-
-
-@pytest.mark.skipif(not os.environ.get("CONVNET_EMU_ALL"), reason="the fetch variant of wgw_kernel: CONVNET_EMU_ALL=1 (~25 s)")
-def test_wide_wgrad_kernel_variant_in_emulation(emu_binary):
-    r = subprocess.run([emu_binary, "wgwvar"], capture_output=True, text=True, timeout=1200)
-    lines = r.stdout.strip().splitlines()
-    assert r.returncode == 0 and lines[-1] == "ALL PASSED" and sum(l.startswith("PASS wgw(spread)") for l in lines) == 2, r.stdout + r.stderr
-
-
 def test_wide_wgrad_kernel_single_block_epilogue_in_emulation(emu_binary):
     """one block per tile (forced: the launch policy splits the reduction at emulation sizes): scaleTargets, scaleOutput and the bias
     row in the kernel's own epilogue, through the 16-byte write-out and through the direct one (F % 4 != 0)"""

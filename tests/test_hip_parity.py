@@ -117,6 +117,9 @@ POOL_CASES = [
     Geom(N=100, C=48, H=25, W=25, F=48, Ky=4, Kx=4, sy=2, sx=2),                     # mnist-conv pool1
     Geom(N=16, C=96, H=110, W=110, F=96, Ky=3, Kx=3, sy=2, sx=2, pady=1, padx=1),    # AlexNet pool1 (exact spatial)
     Geom(N=6, C=3, H=9, W=7, F=3, Ky=3, Kx=2, sy=2, sx=1, pady=1, padx=0),           # rectangular
+    # few channels x few images on a map of >= 400 pixels: the row grid takes the XCD order, the 2 x 2-block undo grid does not
+    Geom(N=16, C=3, H=24, W=24, F=3, Ky=3, Kx=3, sy=2, sx=2, pady=1, padx=1),
+    Geom(N=128, C=3, H=20, W=20, F=3, Ky=3, Kx=3, sy=2, sx=2, pady=1, padx=1),
 ]
 
 

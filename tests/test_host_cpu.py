@@ -306,11 +306,10 @@ def test_bench_kernel_name_matching_and_one_stream_fields():
     assert same("gg_kernel<2,2,2,128,kc,split>", "gg_kernel<2, 2, 2, 128, true, true, false, true>")
     assert same("gg_kernel<1,4,3,64,rc>", "gg_kernel<1, 4, 3, 64, false, true, false>") and not same("gg_kernel<1,4,3,64,rc>", "gg_kernel<1, 4, 3, 64, true, true, false>")
     assert not same("sgd_kernel", "map2_kernel<add_scalar::{lambda")     # truncated names in the PMC file must not raise
-    assert same("gpw_kernel<128x512,split,raw>", "void chip::gpw_kernel<0>(chip::GGParams, chip::GGClassTable)") and same("gpw_kernel<128x512,split,raw>", "chip::gpw_kernel<0>")
-    assert same("gpw_kernel<128x512,split,raw,ring2>", "chip::gpw_kernel<2>") and not same("gpw_kernel<128x512,split,raw,grouped>", "chip::gpw_kernel<0>")
+    assert same("gpw_kernel<128x512,split,raw>", "chip::gpw_kernel(chip::GGParams, chip::GGClassTable)") and same("gpw_kernel<128x512,split,raw>", "chip::gpw_kernel")
     assert not same("gpw_kernel<128x512,split,raw>", "chip::gpw_tail_fix_kernel(chip::GGParams)")
-    assert same("wgw_kernel<256x192,split>", "void chip::wgw_kernel<3, 0>(chip::WGParams)") and not same("wgw_kernel<256x192,split>", "void chip::wgw_kernel<4, 0>(chip::WGParams)")
-    assert same("wgw_kernel<256x256,split,spread>", "chip::wgw_kernel<4, 1>") and not same("wgw_kernel<256x256,split,spread>", "chip::wgw_kernel<4, 0>")
+    assert same("wgw_kernel<256x192,split>", "void chip::wgw_kernel<3>(chip::WGParams)") and not same("wgw_kernel<256x192,split>", "void chip::wgw_kernel<4>(chip::WGParams)")
+    assert same("wgw_kernel<256x256,split>", "chip::wgw_kernel<4>") and not same("wgw_kernel<256x256,split>", "chip::wgw_kernel<3>")
     assert same("gpp_kernel<2,2,2,128,split,raw>", "void chip::gpp_kernel<2, 2, 2, 128, true>(chip::GGParams, chip::GGClassTable)")
     assert b.kernel_peak("gpw_kernel<128x512,split,raw>") == pytest.approx(416.6667, rel=1e-5) and b.kernel_peak("wgw_kernel<256x256,split>") == pytest.approx(416.6667, rel=1e-5)
     rows = [{"kernel": "k", "ms": 2.0, "flops": 4e11, "launches": 4}, {"kernel": "k", "ms": 2.0, "flops": 4e11, "launches": 4},

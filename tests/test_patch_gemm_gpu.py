@@ -17,6 +17,7 @@ from oracle import Geom  # noqa: E402
 from golden_cases import rel_err  # noqa: E402
 
 TOL = 1e-4
+DEFAULT_MODE = 3   # include/convnet_hip.h: gpw_kernel where its launch policy takes the launch, ggp_kernel elsewhere
 
 
 @pytest.fixture(scope="module")
@@ -39,7 +40,7 @@ def patch_mode(request, hip):
     from convnet_amd import _lib
     _lib.lib.convnet_hip_set_patch_mode(1 if request.param == "raw" else 2)
     yield request.param
-    _lib.lib.convnet_hip_set_patch_mode(1)
+    _lib.lib.convnet_hip_set_patch_mode(DEFAULT_MODE)
 
 
 def last_kernel():
@@ -122,16 +123,16 @@ def test_patch_modes_agree_with_ggp_kernel(hip):
         _lib.lib.convnet_hip_set_patch_mode(mode)
         outs.append(hip.conv_up(g, x, w))
         assert last_kernel() == ("gg_kernel(fprop)" if mode == 0 else "gpp_kernel(fprop)")
-    _lib.lib.convnet_hip_set_patch_mode(1)
+    _lib.lib.convnet_hip_set_patch_mode(DEFAULT_MODE)
     assert rel_err(outs[1], outs[0]) < 1e-5 and rel_err(outs[2], outs[0]) < 1e-5
     assert np.array_equal(outs[1], outs[2])   # raw and planes builds: identical operands, identical order
 
 
-# ---- gpw_kernel (patch mode 3: 128 rows x 8 units per block, four waves staging for themselves; 3 x 3 stride-1 gathers with output
-# rows >= 8 wide).  Written at the end of round 4 with the GPU budget spent: its control logic is checked on the CPU
-# (tests/test_patch_wide_cpu.py) but the kernel has not run on hardware yet, so these cases are opt-in until it has
-# (CONVNET_TEST_PATCH_WIDE=1; wrap the run in `timeout`).
-wide = pytest.mark.skipif(not os.environ.get("CONVNET_TEST_PATCH_WIDE"), reason="gpw_kernel not yet validated on hardware (CONVNET_TEST_PATCH_WIDE=1)")
+# ---- gpw_kernel (patch modes 3 / 4: 128 rows x 8 units per block, four waves staging for themselves; 3 x 3 stride-1 gathers with
+# output rows >= 8 wide).  Mode 3 — the library default — adds a launch policy (patch_gemm.hip: wide_plan: the blocks must fill their
+# rounds on the chip, else ggp_kernel); these cases are about the kernel's mechanisms at sizes the policy would leave alone, so they
+# run in mode 4 (no policy); the policy itself: test_wide_launch_policy.  First run on the MI355X in round 5
+# (profiles/r05_wide_kernels.md: the write-out of the 256 accumulator registers needed an explicit element-wise AGPR read).
 WIDE_FPROP = [
     Geom(N=64, C=32, H=9, W=9, F=96, Ky=3, Kx=3, pady=1, padx=1),             # a wrap in almost every tile
     Geom(N=128, C=80, H=13, W=13, F=144, Ky=3, Kx=3, pady=1, padx=1),          # conv3/4 grid, two image blocks, partial row tile, ragged last tile
@@ -150,16 +151,15 @@ WIDE_DGRAD = [
 ]
 
 
-@pytest.fixture(params=[3, 4, 5], ids=["gpw", "gpw_grouped", "gpw_ring2"])
-def wide_mode(request, hip):
-    """gpw_kernel and its two variants (include/convnet_hip.h: patch modes 3 / 4 / 5)"""
+@pytest.fixture
+def wide_mode(hip):
+    """gpw_kernel wherever the shape allows (include/convnet_hip.h: patch mode 4)"""
     from convnet_amd import _lib
-    _lib.lib.convnet_hip_set_patch_mode(request.param)
+    _lib.lib.convnet_hip_set_patch_mode(4)
     yield
-    _lib.lib.convnet_hip_set_patch_mode(1)
+    _lib.lib.convnet_hip_set_patch_mode(DEFAULT_MODE)
 
 
-@wide
 @pytest.mark.parametrize("g", WIDE_FPROP, ids=_id)
 def test_wide_fprop_vs_oracle(hip, wide_mode, g):
     rng = np.random.default_rng(31)
@@ -171,7 +171,6 @@ def test_wide_fprop_vs_oracle(hip, wide_mode, g):
         assert rel_err(got, oracle.port.conv_up(g, x, w, t0.copy(), st)) < TOL
 
 
-@wide
 @pytest.mark.parametrize("g", WIDE_DGRAD, ids=_id)
 def test_wide_dgrad_vs_oracle(hip, wide_mode, g):
     rng = np.random.default_rng(32)
@@ -183,7 +182,6 @@ def test_wide_dgrad_vs_oracle(hip, wide_mode, g):
         assert rel_err(got, oracle.port.conv_down(g, dy, w, t0.copy(), st)) < TOL
 
 
-@wide
 def test_wide_agrees_with_gpp_raw(hip):
     """Same operand splits, same six products, same order along k (cb, tap row, tap) — up to the split-K partition, which each kernel
     picks for its own tile count: agreement to accumulation rounding."""
@@ -192,8 +190,37 @@ def test_wide_agrees_with_gpp_raw(hip):
     rng = np.random.default_rng(33)
     x, w = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape())
     outs = []
-    for mode in (1, 3):
+    for mode in (1, 4):
         _lib.lib.convnet_hip_set_patch_mode(mode)
         outs.append(hip.conv_up(g, x, w))
-    _lib.lib.convnet_hip_set_patch_mode(1)
+        assert last_kernel() == ("gpp_kernel(fprop)" if mode == 1 else "gpw_kernel(fprop)")
+    _lib.lib.convnet_hip_set_patch_mode(DEFAULT_MODE)
     assert rel_err(outs[1], outs[0]) < 1e-5
+
+
+def test_wide_launch_policy(hip):
+    """Mode 3, the default: gpw_kernel takes the launches that fill their rounds on the chip (conv4 at 256 images: 255 tiles on 256
+    CUs; conv5 fprop: 122 tiles in two K-ranges), leaves the others to ggp_kernel (conv3 dgrad: 170 tiles, three K-ranges over two
+    rounds measured slower than ggp_kernel's tail split; small problems) — and both give the oracle's result."""
+    from convnet_amd import _lib
+    assert _lib.lib.convnet_hip_get_patch_mode() == DEFAULT_MODE
+    rng = np.random.default_rng(34)
+    takes = [
+        (Geom(N=256, C=384, H=13, W=13, F=256, Ky=3, Kx=3), "fprop", True),                   # conv5 fprop: 122 tiles x 2 K-ranges
+        (Geom(N=256, C=256, H=13, W=13, F=384, Ky=3, Kx=3, pady=1, padx=1), "dgrad", False),  # conv3 dgrad: 170 tiles
+        (Geom(N=64, C=32, H=9, W=9, F=96, Ky=3, Kx=3, pady=1, padx=1), "fprop", False),       # 11 tiles
+    ]
+    for g, which, wide_expected in takes:
+        w = rnd(rng, g.filt_shape())
+        if which == "fprop":
+            x = rnd(rng, g.in_shape())
+            got, ref = hip.conv_up(g, x, w), None
+            assert last_kernel() == ("gpw_kernel(fprop)" if wide_expected else "gg_kernel(fprop)"), (g, last_kernel())
+            if g.N * g.C * g.F < 10 ** 7:
+                ref = oracle.port.conv_up(g, x, w)
+        else:
+            dy = rnd(rng, g.out_shape())
+            got, ref = hip.conv_down(g, dy, w), None
+            assert last_kernel() == ("gpw_kernel(dgrad)" if wide_expected else "gg_kernel(dgrad)"), (g, last_kernel())
+        if ref is not None:
+            assert rel_err(got, ref) < TOL

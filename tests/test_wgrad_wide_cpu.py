@@ -21,11 +21,11 @@ READ_B, PAIR_B, READ_A, PAIR_A, FETCH, WALK_BEGIN, WALK_STEP = 1, 2, 3, 4, 5, 6,
 DUMP = r'''
 #include <cstdio>
 #include "wgrad_wide_schedule.h"
-template <int NTL, int FV> void dump() {
-  using S = chip::wgw::Schedule<NTL, FV>;
+template <int NTL> void dump() {
+  using S = chip::wgw::Schedule<NTL>;
   constexpr S s{};
-  static_assert(chip::wgw::schedule_ok<NTL, FV>(), "rules");
-  std::printf("{\"NTL\":%d,\"FV\":%d,\"COLS\":%d,\"G\":%d,\"NSLOT\":%d,\"GB\":%d,\"NA\":%d,\"NB\":%d,\"units\":[", NTL, FV, S::COLS, S::G, S::NSLOT, S::GB, S::NA, S::NB);
+  static_assert(chip::wgw::schedule_ok<NTL>(), "rules");
+  std::printf("{\"NTL\":%d,\"COLS\":%d,\"G\":%d,\"NSLOT\":%d,\"GB\":%d,\"NA\":%d,\"NB\":%d,\"units\":[", NTL, S::COLS, S::G, S::NSLOT, S::GB, S::NA, S::NB);
   for (int g = 0; g < S::G; ++g) {
     std::printf("%s[", g ? "," : "");
     for (int i = 0; i < s.n[g]; ++i) std::printf("%s[%d,%d,%d,%d]", i ? "," : "", s.u[g][i].kind, s.u[g][i].a, s.u[g][i].b, s.u[g][i].c);
@@ -33,7 +33,7 @@ template <int NTL, int FV> void dump() {
   }
   std::printf("]}\n");
 }
-int main() { dump<3, 0>(); dump<4, 0>(); dump<3, 1>(); dump<4, 1>(); }
+int main() { dump<3>(); dump<4>(); }
 '''
 
 
@@ -44,7 +44,7 @@ def schedules(tmp_path_factory):
     src.write_text(DUMP)
     subprocess.run(["g++", "-std=c++17", "-I", CSRC, str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
-    return {(s["NTL"], s["FV"]): s for s in map(json.loads, out.strip().splitlines())}
+    return {s["NTL"]: s for s in map(json.loads, out.strip().splitlines())}
 
 
 def run_wave(S, A, B, lazy):
@@ -157,10 +157,9 @@ def run_wave(S, A, B, lazy):
 
 @pytest.mark.parametrize("lazy", [False, True], ids=["eager", "lazy"])
 @pytest.mark.parametrize("nchunks", [1, 2, 5])
-@pytest.mark.parametrize("fv", [0, 1], ids=["fetch_first", "fetch_spread"])
 @pytest.mark.parametrize("ntl", [3, 4])
-def test_chunk_loop_of_the_real_schedule(schedules, ntl, fv, nchunks, lazy):
-    S = schedules[(ntl, fv)]
+def test_chunk_loop_of_the_real_schedule(schedules, ntl, nchunks, lazy):
+    S = schedules[ntl]
     rng = np.random.default_rng(7)
     A = rng.standard_normal((nchunks, 4, 32))
     B = rng.standard_normal((nchunks, ntl, 32))
