@@ -8,12 +8,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libconvnet_hip.so")
-SOURCES = ["state.hip", "gather_gemm.hip", "patch_gemm.hip", "wgrad_wide.hip", "pool_norm.hip", "elementwise.hip", "input_staging.hip", "comm.hip", "rccl_abi_check.hip"]
+SOURCES = ["state.hip", "gather_gemm.hip", "patch_gemm.hip", "wgrad_wide.hip", "fewc_conv.hip", "pool_norm.hip", "elementwise.hip", "input_staging.hip", "comm.hip", "rccl_abi_check.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-inline-asm"]
 # Per-file additions.  patch_gemm.hip: the SLP vectoriser packs the split's fp32 subtractions into v_pk_add_f32 (+ the v_mov / s_nop
 # that feed them) — fewer instructions on paper, but beside MFMAs a packed fp32 op costs more issue time than the two plain ones
 # (MI355X_MICROARCH.md), and gpw_kernel's one wave per SIMD has nobody to hide it: 177 instead of 191 VALU + 10 s_nop per chunk.
-FILE_FLAGS = {"patch_gemm.hip": ["-fno-slp-vectorize"], "wgrad_wide.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"patch_gemm.hip": ["-fno-slp-vectorize"], "wgrad_wide.hip": ["-fno-slp-vectorize"], "fewc_conv.hip": ["-fno-slp-vectorize"]}
 # CONVNET_BUILD_NOSLP=1: the same for gather_gemm.hip (ggp_kernel's consumers and wg_kernel run the same split) — an A/B for the next
 # round with hardware, not the product build: the default kernels were measured and parity-tested as compiled without it.
 if os.environ.get("CONVNET_BUILD_NOSLP"):

@@ -512,6 +512,11 @@ void filter_planes_gk_launch(const float* W, void* out, int F, int K, int KP, in
 bool patch_shape_ok(GGParams& p, size_t dst_elems);
 void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, const PatchBank& bank);
 
+// gfc_kernel (fewc_conv.hip): conv fprop of a few-channel, wide-filter, stride-2 layer (AlexNet conv1) as a patch-resident gather-GEMM
+// with the filter bank resident in LDS; takes the launch and returns true where the shape is of that kind
+bool gfc_try(const float* images, const float* filters, const float* bias, float* targets, int N, int C, int H, int W, int F, int Ky, int Kx,
+             int sy, int sx, int pady, int padx, int My, int Mx, float scaleTargets, int relu, double flops);
+
 // -------------------------------------------------------------------------------------------------
 // wg_kernel / wgw_kernel: dW[k, f] over the (pixel, image) reduction (gather_gemm.hip, wgrad_wide.hip).
 // -------------------------------------------------------------------------------------------------

@@ -1889,6 +1889,10 @@ void conv_up_impl(cudamat* images, cudamat* filters, cudamat* bias, cudamat* tar
   p.DW = g.Mx; p.DP = g.My * g.Mx; p.dsy = 1; p.dsx = 1; p.dy0 = 0; p.dx0 = 0;
   p.scaleTargets = scaleTargets; p.relu = relu;
   const bool vec = g.N % 4 == 0 && g.F % 4 == 0 && aligned16(p.A) && aligned16(p.src) && aligned16(p.dst);
+  if (vec && gg_presplit_mode() && gg_producer_mode() &&
+      gfc_try(images->data_device, filters->data_device, p.bias, targets->data_device, g.N, g.C, g.H, g.W, g.F, g.Ky, g.Kx, g.sy, g.sx, -g.py, -g.px,
+              g.My, g.Mx, scaleTargets, relu, 2.0 * g.N * p.G * (double)g.F * p.K))
+    return;
   if (vec && gg_presplit_mode() && gg_producer_mode() && g.C % BK != 0 && g.F > 32 && CHIP_KNOB("CONVNET_GG_GK", 1) &&
       (size_t)g.C * g.H * g.W * g.N < (size_t(1) << 30)) {
     // few input channels (conv1: C = 3): the producer-wave kernel in the bank's own k order, k-row sources from a table

@@ -32,7 +32,8 @@ const float* zero_page() {
 }
 int matrix_path() { return 1; }
 void set_last_error(const char*) {}
-void note_kernel(const char*, double, int, int) {}
+const char* g_last_kernel = "";
+void note_kernel(const char* name, double, int, int) { g_last_kernel = name; }
 KernelTimer::KernelTimer(const char*, const char*, double, double, double) : slot(-1) {}
 KernelTimer::~KernelTimer() {}
 }  // namespace chip
@@ -238,7 +239,7 @@ static void abi_conv_case(const Geo& g, const char* which) {
             ref[((size_t)(f * My + oy) * Mx + ox) * g.N + n] = s;
           }
     convUp(&mx, &mw, &my, &sx, &sw, &sy, desc(g), 0.f);
-    verdict("abi convUp " + gname(g), rel_err(y, ref), true);
+    verdict("abi convUp " + gname(g) + " [" + chip::g_last_kernel + "]", rel_err(y, ref), true);
   } else if (what == "down") {
     std::vector<double> ref((size_t)g.C * g.H * g.W * g.N);
     for (int c = 0; c < g.C; ++c)
@@ -393,8 +394,10 @@ int main(int argc, char** argv) {
   if (what == "abi" || all || quick) {   // the default kernels through the C ABI: the calibration of the harness (green on hardware)
     abi_conv_case(Geo{64, 16, 9, 9, 128, 3, 3, 1, 1, 1}, "up");      // ggp_kernel<2,2,2,128>, pre-split filter planes
     abi_conv_case(Geo{32, 16, 9, 9, 128, 3, 3, 1, 1, 1}, "outp");    // wg_kernel<2,2,2,2>, K = 144: bias row in the second k tile
+    abi_conv_case(Geo{64, 3, 15, 15, 96, 7, 7, 2, 2, 1}, "up");      // conv1 type: gfc_kernel (patch-resident, filter bank in LDS), 12 tiles on 4 blocks
     if (!quick) {
-      abi_conv_case(Geo{64, 3, 15, 15, 96, 7, 7, 2, 2, 1}, "up");      // conv1 type: generic-k order on ggp_kernel<1,4,3,64>
+      abi_conv_case(Geo{48, 3, 15, 15, 96, 7, 7, 2, 2, 1}, "up");      // conv1 type, N % 32 != 0: generic-k order on ggp_kernel<1,4,3,64>
+      abi_conv_case(Geo{32, 3, 27, 27, 80, 7, 7, 2, 2, 1}, "up");      // conv1 type: gfc_kernel, two column groups (12 = 8 + 4 pixels), 80 of 96 rows, 24 tiles on 4 blocks
       abi_conv_case(Geo{64, 128, 9, 9, 32, 3, 3, 1, 1, 1}, "down");    // one stride class
       abi_conv_case(Geo{64, 96, 11, 11, 32, 5, 5, 2, 2, 0}, "down");   // conv2 type: four stride classes in one launch
       abi_conv_case(Geo{32, 3, 15, 15, 96, 7, 7, 2, 2, 1}, "outp");    // conv1 type: the 160 x 96 tile of 16 x 16 MFMAs, bias row in a padding row

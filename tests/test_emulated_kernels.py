@@ -27,7 +27,7 @@ def _clang():
     return None
 
 
-SOURCES = ["gather_gemm.hip", "patch_gemm.hip", "wgrad_wide.hip", "pool_norm.hip", "elementwise.hip"]
+SOURCES = ["gather_gemm.hip", "patch_gemm.hip", "wgrad_wide.hip", "fewc_conv.hip", "pool_norm.hip", "elementwise.hip"]
 
 
 @pytest.fixture(scope="module")
