@@ -143,6 +143,20 @@ def live_pmc_traffic(kernel, args):
             if not vals:
                 return None
             sums[counter] = sum(vals) / len(vals)
+            # the same pass's kernel trace: rocprofv3's own duration of every launch of the family (dispatches are serialised under
+            # counter collection: each launch alone on the chip) — the second clock beside the HIP-event spans of the timed region
+            tr = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith("kernel_trace.csv")]
+            if tr and "durs" not in sums:
+                durs = []
+                try:
+                    with open(tr[0]) as f:
+                        for row in csv.DictReader(f):
+                            if _same_kernel(kernel, row["Kernel_Name"].split("(")[0].replace("void ", "")):
+                                durs.append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+                except (OSError, KeyError, ValueError):
+                    durs = []   # (the traffic figure does not depend on it)
+                if durs:
+                    sums["durs"] = sum(durs) / len(durs) * 1e-6   # ns -> ms
     except (OSError, subprocess.SubprocessError, KeyError, ValueError):
         return None
     finally:
@@ -150,6 +164,7 @@ def live_pmc_traffic(kernel, args):
     rd, wr = 2 * 1024 * sums["FETCH_SIZE"], 1024 * sums["WRITE_SIZE"]
     return {"traffic": round(rd + wr), "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, fabric side: Infinity-Cache hits included)",
             "traffic_read": round(rd), "traffic_write": round(wr),
+            **({"rocprof_avg_launch_ms": round(sums["durs"], 4)} if "durs" in sums else {}),
             "traffic_source": "measured in this run: two rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE separately) of the same "
                               "workload, 3 steps each, after the timed region"}
 
@@ -275,7 +290,7 @@ def self_launch(args):
     import subprocess
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < args.gpus:
+    if have < args.gpus and not (args.share_device and have >= 1):
         sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs (one process per GPU), this box has {have}; "
                          f"nothing was run\n")
         return 2
@@ -313,6 +328,10 @@ def main():
     ap.add_argument("--transport", default="torch", choices=["torch", "abi"],
                     help="gradient exchange through torch.distributed collectives (default) or through the library's own "
                          "convnet_hip_comm_* entries (the path a C/C++ host drives)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="TEST flag: all ranks of --gpus N on GPU 0, the gradient exchange over gloo instead of RCCL (RCCL refuses two ranks on "
+                         "one device) — the self-launch, the N-rank control flow, the strong leg and the line format on a 1-GPU box; the "
+                         "numbers it prints are not a measurement of anything")
     ap.add_argument("--strong-selftest", action="store_true",
                     help="run the `strong` leg (normally only with more than one rank) on one rank too; needs --force-exchange")
     ap.add_argument("--global-batch", type=int, default=0,
@@ -348,7 +367,9 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_device:
+        args.transport = "torch"   # (over gloo, below)
     if world != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; nothing was run\n")
         sys.exit(2)
@@ -366,7 +387,7 @@ def main():
         # --transport abi: the library owns the ONE RCCL communicator of the process (what a C/C++ host has); torch.distributed only
         # carries the 128-byte id, rendezvous and the timing reductions, over gloo.  (Round 3 created torch's NCCL group here too: two
         # RCCL communicators in one process cost 20 % of every kernel, profiles/r03_bench_dp1_abi.json.)
-        if args.transport == "abi":
+        if args.transport == "abi" or args.share_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -515,6 +536,17 @@ def main():
                       "exchange_exposed_ms": round(1e3 * (times["with_exchange"] - times["compute_only"]) / args.steps, 3),
                       "rccl_ranks": strong_ranks}
 
+    # every replica must hold the same parameters after the same steps (the exchange's result is identical on all ranks and the
+    # optimizer is deterministic): checked on the weak run's net, reported on the line
+    replicas_identical = None
+    if dist.is_initialized() and world > 1:
+        import hashlib
+        torch.cuda.synchronize()
+        digest = hashlib.sha1(net.parameters_.ToNumpy().tobytes()).hexdigest()
+        digests = [None] * world
+        dist.all_gather_object(digests, digest)
+        replicas_identical = all(d == digests[0] for d in digests)
+
     if rank == 0:
         images = args.batch * world * args.steps
         value = images / dt
@@ -565,6 +597,12 @@ def main():
                 "dominant_by": "one-stream time per step (each launch alone on the chip)" if alone_ms else "time in the timed region",
                 "vs_fp32_instruction_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
                 **traffic_fields,
+                # two clocks for the same family: `avg_launch_ms` = HIP-event span inside the timed region (with a second stream it
+                # includes waiting for CUs the other stream holds); `rocprof_avg_launch_ms` = rocprofv3's kernel duration in the PMC
+                # child pass (every launch alone); either gives a fraction from `flops_per_launch` and `peak`
+                **({"rocprof_frac": round(dom["flops"] / dom["launches"] / (traffic_fields["rocprof_avg_launch_ms"] * 1e-3) / 1e12 / peak, 4),
+                    "clocks": "avg_launch_ms: HIP events in the timed region; rocprof_avg_launch_ms: rocprofv3 kernel trace, launches serialised"}
+                   if traffic_fields.get("rocprof_avg_launch_ms") else {}),
                 "flops_per_launch": dom["flops"] / dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                 "launches": dom["launches"], "sampled_steps": timed_steps,
                 "all_mfma_kernels": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
@@ -613,6 +651,12 @@ def main():
         }
         if strong_obj is not None:
             out["strong"] = strong_obj
+            # SURVEY 8(d) config 4 — AlexNet at a GLOBAL batch of 256 on N GPUs — at top level beside the weak `value` (global 256 x N)
+            out["config4_value"] = strong_obj["value"]
+        if replicas_identical is not None:
+            out["replicas_identical"] = replicas_identical
+        if args.share_device:
+            out["share_device"] = "TEST run: every rank on GPU 0, exchange over gloo — not a measurement"
         if other is not None:
             out["fp32_mfma_path" if other["matrix_path"] == "fp32" else "split_path"] = other
         if world == 1 and not args.no_cpu_baseline:
