@@ -256,7 +256,7 @@ def cpu_baseline(sample_n=6):   # ~13 s of CPU work on the 256-core GPU box (N=2
                       f"(eigenmat.cc:2284-2298), only its pooling/softmax loops use OpenMP"}
 
 
-def ref_host_leg(args, dp=False):
+def ref_host_leg(args, dp=False, defer=True):
     """The north-star driver on the same clock: the reference's UNMODIFIED C++ host (src/convnet.cc ConvNet::TrainOneBatch over its own
     Layer / Edge / SGDOptimizer / Matrix, compiled from /root/reference by oracle/Makefile into oracle/_ref/libref_host_hip.so) linked
     to this library, stepping the same model and batch.  Reported beside the product number, never part of it: it runs after the
@@ -270,12 +270,14 @@ def ref_host_leg(args, dp=False):
     try:
         # the C++ host opts into the bf16-split products the way INTEGRATION.md §2 says (one environment variable or one call): the
         # library's own default at the ABI is the IEEE fp32 matrix instruction
-        env = dict(os.environ, CONVNET_GG_SPLIT="1" if args.matrix_path == "split" else "0")
+        # ... and, the same way, into deferred epilogues (convnet_hip_set_deferred_epilogues / CONVNET_DEFER_EPILOGUES): the unfused call
+        # sequence of src/conv_edge.cc + src/layer.cc then runs as fused launches, bit for bit the eager results
+        env = dict(os.environ, CONVNET_GG_SPLIT="1" if args.matrix_path == "split" else "0", CONVNET_DEFER_EPILOGUES="1" if defer else "0")
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         j = json.loads(line)
         return {"value": round(j["value"], 2), "unit": "images/sec", "ms_per_step": round(j["ms_per_step"], 3), "steps": j["steps"],
-                "warmup": j["warmup"], "matrix_path": args.matrix_path,
+                "warmup": j["warmup"], "matrix_path": args.matrix_path, "deferred_epilogues": bool(defer),
                 "host": "reference src/*.cc unmodified -> reference Matrix (src/matrix.cc) -> this library; "
                                                "unfused cudamat call sequence, one metric read-back per step",
                 "last_loss": j.get("last_loss")}
@@ -666,6 +668,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
         if world == 1 and not args.no_ref_host and args.model in ("alexnet", "alexnet_nin") and not args.staged_input:
             out["ref_host"] = ref_host_leg(args)
+            out["ref_host_eager"] = ref_host_leg(args, defer=False)   # the same host with every unfused call launched as it is made
             # ... and the same host with the reference's data-parallel step re-expressed on the library's exchange entries
             # (SeamDPNet), a world of one rank: what the exchange plumbing costs a C++ host
             out["ref_host_dp"] = ref_host_leg(args, dp=True)

@@ -95,6 +95,9 @@ def _load():
     sig("convnet_hip_get_matrix_path", I)
     sig("convnet_hip_set_patch_mode", None, I)
     sig("convnet_hip_get_patch_mode", I)
+    sig("convnet_hip_set_deferred_epilogues", None, I)
+    sig("convnet_hip_get_deferred_epilogues", I)
+    sig("convnet_hip_deferred_absorbed", ctypes.c_long)
     sig("convnet_hip_set_wgrad_tile", None, I)
     sig("convnet_hip_get_wgrad_tile", I)
     sig("get_last_cuda_error", ctypes.c_char_p)

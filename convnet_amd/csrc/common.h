@@ -34,6 +34,30 @@ struct KernelTimer {
   int slot;
 };
 
+// Deferred epilogues (state.hip; convnet_hip_set_deferred_epilogues, include/convnet_hip.h): with the switch on, convUp / convDown /
+// MaxPoolUndo / ResponseNormCrossMap are not launched when they are called but parked — ONE call deep — until the next library call.
+// If that call is the element-wise pass the reference's host issues right behind them on the same matrix (add_row_vec of the shared bias
+// and lower_bound_scalar(0): src/conv_edge.cc:138-149, src/layer.cc:549-551; apply_rectified_linear_deriv: src/layer.cc:556-558), it is
+// absorbed into the parked call's fused epilogue; any other call flushes the parked one first (stream() does it, so no entry point can
+// overtake it).  Off by default: the unfused entries then run exactly when called.
+struct PendingOp {
+  int kind;            // 0 none, 1 conv up, 2 conv down, 3 max-pool undo, 4 response norm
+  cudamat m[4];        // copies of the call's operands (the host may reshape its structs in between)
+  Shape4D s[3];
+  ConvDesc desc;
+  float scaleTargets;
+  int i0, i1;          // response norm: numFilters, sizeF
+  float f0, f1;        //                addScale, powScale
+  bool b0;             //                blocked
+  cudamat bias, mask;  // what has been absorbed so far
+  int has_bias, relu, has_mask;
+  void (*launch)(PendingOp&);
+};
+bool defer_begin(int kind, void (*launch)(PendingOp&));   // false: switch off (the caller launches at once); true: fill pending()
+PendingOp& pending();
+void flush_pending();
+extern long g_absorbed;
+
 [[noreturn]] inline void fatal(const char* what, const char* file, int line) {
   // Same policy as the reference's conv back-end: shape/HIP errors are unrecoverable
   // (cudamat_conv_gemm.cu:35-42 getLastCudaError -> exit(EXIT_FAILURE)).

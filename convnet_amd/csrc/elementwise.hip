@@ -614,7 +614,50 @@ using namespace chip;
 
 extern "C" {
 
-int add_row_vec(cudamat* mat, cudamat* vec, cudamat* target) { return add_row(mat, vec, target, 1.0f); }
+// ---- deferred epilogues (common.h: PendingOp): does this element-wise call continue the parked one? ---------------------------------
+namespace {
+inline bool same_mat(const cudamat* a, const cudamat& b) { return a->on_device && a->data_device == b.data_device && numel(a) == numel(&b); }
+// add_row_vec(T viewed as (N*M, F), bias(1, F), T) behind convUp(..., T): the shared bias of src/conv_edge.cc:145-148
+bool absorb_bias(cudamat* mat, cudamat* vec, cudamat* target) {
+  PendingOp& o = pending();
+  if (o.kind != 1 || o.has_bias || o.relu || mat != target && mat->data_device != target->data_device) return false;
+  const int F = o.desc.num_output_channels;
+  if (!same_mat(mat, o.m[2]) || !same_mat(target, o.m[2]) || mat->is_trans || !vec->on_device || (int)numel(vec) != F || mat->size[1] != F) return false;
+  o.bias = *vec;
+  o.has_bias = 1;
+  ++g_absorbed;
+  return true;
+}
+// lower_bound_scalar(T, 0, T) behind convUp(..., T) [+ bias] or ResponseNormCrossMap(..., T): the ReLU of src/layer.cc:549-551
+bool absorb_relu(cudamat* mat, float val, cudamat* target) {
+  PendingOp& o = pending();
+  if ((o.kind != 1 && o.kind != 4) || o.relu || val != 0.f) return false;
+  const cudamat& t = o.kind == 1 ? o.m[2] : o.m[1];
+  if (!same_mat(mat, t) || !same_mat(target, t)) return false;
+  o.relu = 1;
+  flush_pending();   // nothing more can join
+  ++g_absorbed;
+  return true;
+}
+// apply_rectified_linear_deriv(D, S, D) behind convDown(..., D) or MaxPoolUndo(images = S, ..., D): the ReLU' of src/layer.cc:556-558
+bool absorb_relu_deriv(cudamat* deriv, cudamat* state, cudamat* target) {
+  PendingOp& o = pending();
+  if ((o.kind != 2 && o.kind != 3) || o.has_mask || !state->on_device || numel(state) != numel(deriv)) return false;
+  const cudamat& t = o.kind == 2 ? o.m[2] : o.m[3];
+  if (!same_mat(deriv, t) || !same_mat(target, t)) return false;
+  if (o.kind == 3 && !same_mat(state, o.m[0])) return false;   // the pooling kernel masks with its own input
+  o.mask = *state;
+  o.has_mask = 1;
+  flush_pending();
+  ++g_absorbed;
+  return true;
+}
+}  // namespace
+
+int add_row_vec(cudamat* mat, cudamat* vec, cudamat* target) {
+  if (absorb_bias(mat, vec, target)) return 0;
+  return add_row(mat, vec, target, 1.0f);
+}
 int add_row_mult(cudamat* mat, cudamat* vec, cudamat* target, float mult) { return add_row(mat, vec, target, mult); }
 
 int sum_by_axis(cudamat* mat, cudamat* target, int axis, float mult, float p) { return axis_sum<false>(mat, target, axis, mult, p); }
@@ -653,12 +696,14 @@ int sgd_momentum_step_normlimit(cudamat* grad, cudamat* param, cudamat* history,
 }
 
 int lower_bound_scalar(cudamat* mat, float val, cudamat* target) {
+  if (absorb_relu(mat, val, target)) return 0;
   return map2(target, mat, nullptr, [val] __device__(float x, float) { return x > val ? x : val; });
 }
 int upper_bound_mod_scalar(cudamat* mat, float val, cudamat* target) {
   return map2(target, mat, nullptr, [val] __device__(float x, float) { return x > val ? val : (x < -val ? -val : x); });
 }
 int apply_rectified_linear_deriv(cudamat* mat1, cudamat* mat2, cudamat* target) {
+  if (absorb_relu_deriv(mat1, mat2, target)) return 0;
   return map2(target, mat1, mat2, [] __device__(float d, float s) { return s > 0.f ? d : 0.f * d; });
 }
 int assign_scalar(cudamat* mat, float alpha) {

@@ -1966,13 +1966,35 @@ extern "C" void convnet_hip_debug_set_gg_trace(unsigned long long* dev_buf) {
 
 extern "C" {
 
+// deferred epilogues (common.h: PendingOp): the parked forms of convUp / convDown
+static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* ds, Shape4D* fs, Shape4D* ts, const ConvDesc& d,
+                           float scaleTargets, cudamat* mask, float post_scale);
+static void launch_conv_up(PendingOp& o) {
+  conv_up_impl(&o.m[0], &o.m[1], o.has_bias ? &o.bias : nullptr, &o.m[2], &o.s[0], &o.s[1], &o.s[2], o.desc, o.scaleTargets, o.relu);
+}
+static void launch_conv_down(PendingOp& o) {
+  conv_down_impl(&o.m[0], &o.m[1], &o.m[2], &o.s[0], &o.s[1], &o.s[2], o.desc, o.scaleTargets, o.has_mask ? &o.mask : nullptr, 1.0f);
+}
+static bool park_conv(int kind, void (*launch)(PendingOp&), cudamat* a, cudamat* b, cudamat* c, Shape4D* sa, Shape4D* sb, Shape4D* sc, const ConvDesc& d,
+                      float scaleTargets) {
+  if (!defer_begin(kind, launch)) return false;
+  PendingOp& o = pending();
+  o.m[0] = *a; o.m[1] = *b; o.m[2] = *c;
+  o.s[0] = *sa; o.s[1] = *sb; o.s[2] = *sc;
+  o.desc = d;
+  o.scaleTargets = scaleTargets;
+  return true;
+}
+
 void convUpGemm(cudamat* images, cudamat* filters, cudamat* targets, Shape4D* is, Shape4D* fs, Shape4D* ts, ConvDesc d,
                 float scaleTargets) {
+  if (park_conv(1, launch_conv_up, images, filters, targets, is, fs, ts, d, scaleTargets)) return;
   conv_up_impl(images, filters, nullptr, targets, is, fs, ts, d, scaleTargets, 0);
 }
 
 void convUp(cudamat* images, cudamat* filters, cudamat* targets, Shape4D* is, Shape4D* fs, Shape4D* ts, ConvDesc d,
             float scaleTargets) {
+  if (park_conv(1, launch_conv_up, images, filters, targets, is, fs, ts, d, scaleTargets)) return;
   conv_up_impl(images, filters, nullptr, targets, is, fs, ts, d, scaleTargets, 0);
 }
 
@@ -2108,11 +2130,13 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
 
 void convDownGemm(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* ds, Shape4D* fs, Shape4D* ts, ConvDesc d,
                   float scaleTargets) {
+  if (park_conv(2, launch_conv_down, derivs, filters, targets, ds, fs, ts, d, scaleTargets)) return;
   conv_down_impl(derivs, filters, targets, ds, fs, ts, d, scaleTargets, nullptr, 1.0f);
 }
 
 void convDown(cudamat* derivs, cudamat* filters, cudamat* targets, Shape4D* ds, Shape4D* fs, Shape4D* ts, ConvDesc d,
               float scaleTargets) {
+  if (park_conv(2, launch_conv_down, derivs, filters, targets, ds, fs, ts, d, scaleTargets)) return;
   conv_down_impl(derivs, filters, targets, ds, fs, ts, d, scaleTargets, nullptr, 1.0f);
 }
 

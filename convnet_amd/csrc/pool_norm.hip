@@ -697,8 +697,23 @@ void AvgPoolGemm(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, Co
 void MaxPool(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, ConvDesc d) { pool_fwd<true>(images, targets, is, ts, d, 0.f, 1.f); }
 void AvgPool(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, ConvDesc d) { pool_fwd<false>(images, targets, is, ts, d, 0.f, 1.f); }
 
+// deferred epilogues (common.h: PendingOp): the parked form of MaxPoolUndo — the ReLU' of the layer below can join it
+static void launch_pool_undo(PendingOp& o) {
+  pool_undo<true>(&o.m[0], &o.m[1], &o.m[2], &o.m[3], &o.s[0], &o.s[1], o.desc, o.scaleTargets, o.has_mask != 0);
+}
+static bool park_pool_undo(cudamat* images, cudamat* maxGrads, cudamat* maxActs, cudamat* targets, Shape4D* images_shape, Shape4D* maxGrads_shape,
+                           const ConvDesc& d, float scaleTargets) {
+  if (!defer_begin(3, launch_pool_undo)) return false;
+  PendingOp& o = pending();
+  o.m[0] = *images; o.m[1] = *maxGrads; o.m[2] = *maxActs; o.m[3] = *targets;
+  o.s[0] = *images_shape; o.s[1] = *maxGrads_shape;
+  o.desc = d;
+  o.scaleTargets = scaleTargets;
+  return true;
+}
 void MaxPoolUndoGemm(cudamat* images, cudamat* maxGrads, cudamat* maxActs, cudamat* targets, Shape4D* images_shape, Shape4D* maxGrads_shape,
                      ConvDesc d, float scaleTargets) {
+  if (park_pool_undo(images, maxGrads, maxActs, targets, images_shape, maxGrads_shape, d, scaleTargets)) return;
   pool_undo<true>(images, maxGrads, maxActs, targets, images_shape, maxGrads_shape, d, scaleTargets);
 }
 void MaxPoolUndoRelu(cudamat* images, cudamat* maxGrads, cudamat* maxActs, cudamat* targets, Shape4D* images_shape,
@@ -707,6 +722,7 @@ void MaxPoolUndoRelu(cudamat* images, cudamat* maxGrads, cudamat* maxActs, cudam
 }
 void MaxPoolUndo(cudamat* images, cudamat* maxGrads, cudamat* maxActs, cudamat* targets, Shape4D* images_shape, Shape4D* maxGrads_shape,
                  ConvDesc d, float scaleTargets) {
+  if (park_pool_undo(images, maxGrads, maxActs, targets, images_shape, maxGrads_shape, d, scaleTargets)) return;
   pool_undo<true>(images, maxGrads, maxActs, targets, images_shape, maxGrads_shape, d, scaleTargets);
 }
 void AvgPoolUndoGemm(cudamat* avgGrads, cudamat* targets, Shape4D* avgGrads_shape, Shape4D* targets_shape, ConvDesc d, float scaleTargets) {
@@ -745,7 +761,14 @@ static void rnorm_fwd_impl(cudamat* images, cudamat* targets, int numFilters, in
   hipLaunchKernelGGL(rnorm_fwd_kernel, dim3(grid_for((locs + 3) / 4 * nseg)), dim3(256), 0, stream(), images->data_device, targets->data_device, locs,
                      numFilters, sizeF, addScale, powScale, blocked, vec, cseg, nseg, relu);
 }
+static void launch_rnorm_fwd(PendingOp& o) { rnorm_fwd_impl(&o.m[0], &o.m[1], o.i0, o.i1, o.f0, o.f1, o.b0, o.relu != 0); }
 void ResponseNormCrossMapGemm(cudamat* images, cudamat* targets, int numFilters, int sizeF, float addScale, float powScale, bool blocked) {
+  if (defer_begin(4, launch_rnorm_fwd)) {   // (the ReLU of a RECTIFIED_LINEAR destination layer can join it)
+    PendingOp& o = pending();
+    o.m[0] = *images; o.m[1] = *targets;
+    o.i0 = numFilters; o.i1 = sizeF; o.f0 = addScale; o.f1 = powScale; o.b0 = blocked;
+    return;
+  }
   rnorm_fwd_impl(images, targets, numFilters, sizeF, addScale, powScale, blocked, false);
 }
 void ResponseNormCrossMapRelu(cudamat* images, cudamat* targets, int numFilters, int sizeF, float addScale, float powScale, bool blocked) {

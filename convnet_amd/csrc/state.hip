@@ -15,7 +15,40 @@ std::string g_last_error;
 ConvnetHipKernelInfo g_info = {"none", 0.0, 0, 1};
 }  // namespace
 
-hipStream_t stream() { return g_stream; }
+// ---- deferred epilogues (common.h: PendingOp) -------------------------------------------------------------------------------------
+namespace {
+int g_defer = -1;   // -1: not decided (first use reads CONVNET_DEFER_EPILOGUES; default off)
+PendingOp g_pending = {};
+bool g_flushing = false;
+inline bool defer_on() {
+  if (g_defer < 0) g_defer = env_int("CONVNET_DEFER_EPILOGUES", 0) != 0 ? 1 : 0;
+  return g_defer != 0;
+}
+}  // namespace
+long g_absorbed = 0;   // element-wise calls absorbed into a parked call so far (elementwise.hip counts; tests read it)
+PendingOp& pending() { return g_pending; }
+void flush_pending() {
+  if (g_pending.kind == 0 || g_flushing) return;
+  PendingOp o = g_pending;
+  g_pending.kind = 0;
+  g_flushing = true;   // (the launch itself asks for the stream)
+  o.launch(o);
+  g_flushing = false;
+}
+bool defer_begin(int kind, void (*launch)(PendingOp&)) {
+  if (!defer_on() || g_flushing) return false;
+  flush_pending();
+  g_pending = PendingOp{};
+  g_pending.kind = kind;
+  g_pending.launch = launch;
+  return true;
+}
+
+// Every launch, copy, event and synchronisation of the library asks for the stream here: a parked call goes out first.
+hipStream_t stream() {
+  flush_pending();
+  return g_stream;
+}
 
 int g_matrix_path = -1;   // -1: not decided yet (first use reads CONVNET_GG_SPLIT; default 0 = IEEE fp32 products)
 int matrix_path() {
@@ -38,9 +71,10 @@ struct Arena {
 std::map<hipStream_t, Arena> g_arena[3];
 
 void* arena_get(int which, size_t bytes, size_t slack) {
+  flush_pending();
   Arena& a = g_arena[which][g_stream];
   if (bytes <= a.cap) return a.p;
-  CHIP_CHECK(hipStreamSynchronize(g_stream));
+  CHIP_CHECK(hipStreamSynchronize(stream()));
   if (a.p) CHIP_CHECK(hipFree(a.p));
   a.cap = ((bytes + slack) >> 20) << 20;
   CHIP_CHECK(hipMalloc(&a.p, a.cap));
@@ -101,12 +135,12 @@ hipEvent_t get_event() {
 KernelTimer::KernelTimer(const char* name, const char* op, double flops, double bytes, double executed) : slot(-1) {
   if (!g_prof_on) return;
   ProfRec r{name, op, flops, bytes, executed > 0.0 ? executed : flops, get_event(), get_event()};
-  CHIP_CHECK(hipEventRecord(r.start, g_stream));
+  CHIP_CHECK(hipEventRecord(r.start, stream()));
   g_prof.push_back(r);
   slot = (int)g_prof.size() - 1;
 }
 KernelTimer::~KernelTimer() {
-  if (slot >= 0) CHIP_CHECK(hipEventRecord(g_prof[slot].stop, g_stream));
+  if (slot >= 0) CHIP_CHECK(hipEventRecord(g_prof[slot].stop, stream()));
 }
 
 __global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
@@ -145,7 +179,16 @@ void convnet_hip_shutdown(void) {
   }
 }
 
-void convnet_hip_set_stream(void* s) { g_stream = (hipStream_t)s; }
+void convnet_hip_set_stream(void* s) {
+  flush_pending();   // a parked call belongs to the stream it was made on
+  g_stream = (hipStream_t)s;
+}
+void convnet_hip_set_deferred_epilogues(int on) {
+  flush_pending();
+  g_defer = on != 0 ? 1 : 0;
+}
+int convnet_hip_get_deferred_epilogues(void) { return defer_on() ? 1 : 0; }
+long convnet_hip_deferred_absorbed(void) { return chip::g_absorbed; }
 void* convnet_hip_get_stream(void) { return (void*)g_stream; }
 
 int convnet_hip_reserve_workspace(size_t bytes) {
@@ -160,7 +203,7 @@ const char* get_last_cuda_error(void) { return g_last_error.c_str(); }
 
 int cuda_set_device(int deviceId) { return hipSetDevice(deviceId) == hipSuccess ? 0 : CUDA_ERROR; }
 
-void cuda_sync_threads(void) { CHIP_CHECK(hipStreamSynchronize(g_stream)); }
+void cuda_sync_threads(void) { CHIP_CHECK(hipStreamSynchronize(stream())); }
 
 static int event_status(hipError_t err) {
   if (err != hipSuccess) {
@@ -170,8 +213,8 @@ static int event_status(hipError_t err) {
   return err != hipSuccess;
 }
 int cuda_create_event(void** t) { return event_status(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(t), hipEventDisableTiming)); }
-int cuda_record_event(void** t) { return event_status(hipEventRecord(*reinterpret_cast<hipEvent_t*>(t), g_stream)); }
-int cuda_synchronize_event(void** t) { return event_status(hipStreamWaitEvent(g_stream, *reinterpret_cast<hipEvent_t*>(t), 0)); }
+int cuda_record_event(void** t) { return event_status(hipEventRecord(*reinterpret_cast<hipEvent_t*>(t), stream())); }
+int cuda_synchronize_event(void** t) { return event_status(hipStreamWaitEvent(stream(), *reinterpret_cast<hipEvent_t*>(t), 0)); }
 // The reference's Matrix destructor releases the texture view of every matrix (src/matrix.cc:~Matrix -> cudamat.cu destroy_tex);
 // this library never binds textures (tex_obj stays 0), so there is nothing to release.
 int destroy_tex(cudamat* mat) {
@@ -193,7 +236,7 @@ void convnet_hip_profile_enable(int on) { g_prof_on = on != 0; }
 // number of bytes written (0 if nothing was recorded or the buffer is too small).
 size_t convnet_hip_profile_report(char* buf, size_t cap) {
   if (g_prof.empty()) return 0;
-  hipStreamSynchronize(g_stream);
+  hipStreamSynchronize(stream());
   struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0, executed = 0; };
   std::map<std::string, Agg> agg;
   for (auto& r : g_prof) {
@@ -228,6 +271,7 @@ int allocate_device_memory(cudamat* mat) {
 }
 
 int free_device_memory(cudamat* mat) {
+  flush_pending();   // (a parked call may read or write this matrix)
   if (mat->owns_data && mat->on_device) {
     if (hipFree(mat->data_device) != hipSuccess) return CUDA_ERROR;
     mat->on_device = 0;
@@ -239,8 +283,8 @@ int free_device_memory(cudamat* mat) {
 int copy_to_host(cudamat* mat) {
   if (!mat->on_device) return ERROR_NOT_ON_DEVICE;
   const size_t bytes = numel(mat) * sizeof(float);
-  if (hipMemcpyAsync(mat->data_host, mat->data_device, bytes, hipMemcpyDeviceToHost, g_stream) != hipSuccess) return CUDA_ERROR;
-  if (hipStreamSynchronize(g_stream) != hipSuccess) return CUDA_ERROR;
+  if (hipMemcpyAsync(mat->data_host, mat->data_device, bytes, hipMemcpyDeviceToHost, stream()) != hipSuccess) return CUDA_ERROR;
+  if (hipStreamSynchronize(stream()) != hipSuccess) return CUDA_ERROR;
   mat->on_host = 1;
   return 0;
 }
@@ -251,8 +295,8 @@ int copy_to_device(cudamat* mat) {
     if (rc) return rc;
   }
   const size_t bytes = numel(mat) * sizeof(float);
-  if (hipMemcpyAsync(mat->data_device, mat->data_host, bytes, hipMemcpyHostToDevice, g_stream) != hipSuccess) return CUDA_ERROR;
-  if (hipStreamSynchronize(g_stream) != hipSuccess) return CUDA_ERROR;
+  if (hipMemcpyAsync(mat->data_device, mat->data_host, bytes, hipMemcpyHostToDevice, stream()) != hipSuccess) return CUDA_ERROR;
+  if (hipStreamSynchronize(stream()) != hipSuccess) return CUDA_ERROR;
   return 0;
 }
 
@@ -260,8 +304,8 @@ int copy_to_host_slice(cudamat* mat, size_t start, size_t end) {
   if (!mat->on_device) return ERROR_NOT_ON_DEVICE;
   if (end > (size_t)mat->size[1] || start > end) return ERROR_INCOMPATIBLE_DIMENSIONS;
   const size_t off = start * mat->size[0], bytes = (end - start) * mat->size[0] * sizeof(float);
-  if (hipMemcpyAsync(mat->data_host + off, mat->data_device + off, bytes, hipMemcpyDeviceToHost, g_stream) != hipSuccess) return CUDA_ERROR;
-  return hipStreamSynchronize(g_stream) == hipSuccess ? 0 : CUDA_ERROR;
+  if (hipMemcpyAsync(mat->data_host + off, mat->data_device + off, bytes, hipMemcpyDeviceToHost, stream()) != hipSuccess) return CUDA_ERROR;
+  return hipStreamSynchronize(stream()) == hipSuccess ? 0 : CUDA_ERROR;
 }
 
 int copy_to_device_slice(cudamat* mat, size_t start, size_t end) {
@@ -273,13 +317,13 @@ int copy_to_device_slice(cudamat* mat, size_t start, size_t end) {
     if (rc) return rc;
   }
   const size_t off = start * mat->size[0], bytes = (end - start) * mat->size[0] * sizeof(float);
-  if (hipMemcpyAsync(mat->data_device + off, mat->data_host + off, bytes, hipMemcpyHostToDevice, g_stream) != hipSuccess) return CUDA_ERROR;
-  return hipStreamSynchronize(g_stream) == hipSuccess ? 0 : CUDA_ERROR;
+  if (hipMemcpyAsync(mat->data_device + off, mat->data_host + off, bytes, hipMemcpyHostToDevice, stream()) != hipSuccess) return CUDA_ERROR;
+  return hipStreamSynchronize(stream()) == hipSuccess ? 0 : CUDA_ERROR;
 }
 
 int copy_on_device(cudamat* mat1, cudamat* mat2) {
   if (mat1->size[0] != mat2->size[0] || mat1->size[1] != mat2->size[1]) return ERROR_INCOMPATIBLE_DIMENSIONS;
-  if (hipMemcpyAsync(mat2->data_device, mat1->data_device, numel(mat1) * sizeof(float), hipMemcpyDeviceToDevice, g_stream) != hipSuccess) return CUDA_ERROR;
+  if (hipMemcpyAsync(mat2->data_device, mat1->data_device, numel(mat1) * sizeof(float), hipMemcpyDeviceToDevice, stream()) != hipSuccess) return CUDA_ERROR;
   return 0;
 }
 
@@ -287,7 +331,7 @@ int copy_transpose(cudamat* source, cudamat* target) {
   if (source->size[0] != target->size[1] || source->size[1] != target->size[0]) return ERROR_INCOMPATIBLE_DIMENSIONS;
   const int rows = source->size[0], cols = source->size[1];
   dim3 grid(divup(rows, 32), divup(cols, 32));
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, g_stream, source->data_device, target->data_device, rows, cols);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream(), source->data_device, target->data_device, rows, cols);
   return launch_status();
 }
 
@@ -344,8 +388,8 @@ int init_empty(cudamat* mat, int m, int n) {
 
 int write_at(cudamat* mat, int row, int col, float val) {
   if (row < 0 || col < 0 || row >= mat->size[0] || col >= mat->size[1]) return ERROR_INCOMPATIBLE_DIMENSIONS;
-  if (hipMemcpyAsync(mat->data_device + (size_t)col * mat->size[0] + row, &val, sizeof(float), hipMemcpyHostToDevice, g_stream) != hipSuccess) return CUDA_ERROR;
-  return hipStreamSynchronize(g_stream) == hipSuccess ? 0 : CUDA_ERROR;
+  if (hipMemcpyAsync(mat->data_device + (size_t)col * mat->size[0] + row, &val, sizeof(float), hipMemcpyHostToDevice, stream()) != hipSuccess) return CUDA_ERROR;
+  return hipStreamSynchronize(stream()) == hipSuccess ? 0 : CUDA_ERROR;
 }
 
 float read_from(cudamat* mat, int row, int col, int* err_code) {
@@ -355,8 +399,8 @@ float read_from(cudamat* mat, int row, int col, int* err_code) {
     return 0.f;
   }
   float v = 0.f;
-  if (hipMemcpyAsync(&v, mat->data_device + (size_t)col * mat->size[0] + row, sizeof(float), hipMemcpyDeviceToHost, g_stream) != hipSuccess ||
-      hipStreamSynchronize(g_stream) != hipSuccess)
+  if (hipMemcpyAsync(&v, mat->data_device + (size_t)col * mat->size[0] + row, sizeof(float), hipMemcpyDeviceToHost, stream()) != hipSuccess ||
+      hipStreamSynchronize(stream()) != hipSuccess)
     *err_code = CUDA_ERROR;
   return v;
 }

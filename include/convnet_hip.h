@@ -129,6 +129,17 @@ int convnet_hip_get_patch_mode(void);
  * Initial value: environment CONVNET_WG_TILE, else 1. */
 void convnet_hip_set_wgrad_tile(int mode);
 int convnet_hip_get_wgrad_tile(void);
+/* Deferred epilogues, for hosts that issue the reference's UNFUSED call sequence (the reference's own src/*.cc): with the switch on,
+ * convUp / convUpGemm, convDown / convDownGemm, MaxPoolUndo / MaxPoolUndoGemm and ResponseNormCrossMap(Gemm) are parked — one call
+ * deep — instead of launched, and the element-wise pass the reference issues right behind them on the same matrix is absorbed into the
+ * parked call's fused epilogue: add_row_vec of the shared bias and lower_bound_scalar(.., 0, ..) behind a convolution
+ * (src/conv_edge.cc:145-148, src/layer.cc:549-551), lower_bound_scalar behind a response normalisation, apply_rectified_linear_deriv
+ * behind convDown or MaxPoolUndo (src/layer.cc:556-558).  ANY other library call launches the parked one first, so results are those
+ * of the eager sequence (bit for bit on finite data: the fused epilogues add, clamp and mask in the same order; a masked-out
+ * derivative is +0 where the eager pass gives 0 * d).  Initial value: environment CONVNET_DEFER_EPILOGUES, else 0. */
+void convnet_hip_set_deferred_epilogues(int on);
+int convnet_hip_get_deferred_epilogues(void);
+long convnet_hip_deferred_absorbed(void);              /* element-wise calls absorbed into a parked call since the library was loaded */
 const char* get_last_cuda_error(void);               /* cudamat.cuh:109 */
 int cuda_set_device(int deviceId);                   /* cudamat.cuh:116 */
 void cuda_sync_threads(void);                        /* cudamat.cuh:123 — synchronises the current stream */

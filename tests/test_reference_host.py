@@ -515,3 +515,31 @@ def test_reference_host_steps_the_full_alexnet_on_this_library(hip_host, tmp_pat
     assert n > 60_000_000                      # the AlexNet-class parameter count (flat, aligned)
     assert np.all(np.isfinite(loss)) and 0 <= correct <= 4 * 32
     assert np.all(loss < 32 * 12.0)            # log(1000) = 6.9 per case at init; no blow-up
+
+
+@pytest.mark.gpu
+def test_reference_host_with_deferred_epilogues_equals_its_eager_run_bit_for_bit(hip_host, golden, tmp_path):
+    """convnet_hip_set_deferred_epilogues(1): the reference's unfused sequence — convUp, add_row_vec, lower_bound_scalar;
+    convDown / MaxPoolUndo, apply_rectified_linear_deriv; ResponseNormCrossMap, lower_bound_scalar (src/conv_edge.cc:138-149,
+    src/layer.cc:549-558) — runs as fused launches behind the SAME C++ host, and the gradient and the trained parameters are those
+    of the eager run, bit for bit (and so within tolerance of the reference's CPU run)."""
+    from convnet_amd import _lib
+    text = small_alexnet()
+    m, d = ref_host.write_configs(tmp_path, text, golden["batch"], golden["num_batches"], golden["seed"])
+    runs = {}
+    for on in (0, 1):
+        _lib.lib.convnet_hip_set_deferred_epilogues(on)
+        before = _lib.lib.convnet_hip_deferred_absorbed()
+        try:
+            g0 = hip_host.gradient(m, d, golden["p0"])
+            absorbed = _lib.lib.convnet_hip_deferred_absorbed() - before
+            p3, correct, loss = hip_host.train(m, d, golden["steps"], golden["p0"])
+        finally:
+            _lib.lib.convnet_hip_set_deferred_epilogues(0)
+        runs[on] = (g0, p3, correct, np.asarray(loss), absorbed)
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    assert runs[0][2] == runs[1][2] and np.array_equal(runs[0][3], runs[1][3])
+    assert_flat_close(runs[1][1], golden["p3"], text, TOL, "parameters after 3 steps, deferred epilogues")
+    # ... and it really fused, in one forward + backward pass of the AlexNet topology: bias + ReLU of five convolutions, the ReLU of two
+    # response normalisations, the ReLU' behind four convDown and three MaxPoolUndo
+    assert runs[0][4] == 0 and runs[1][4] >= 12, runs[1][4]   # (19 if every one of them joins)
