@@ -48,6 +48,7 @@ Rccl g_rccl;
 ncclComm_t g_comm = nullptr;
 int g_rank = 0, g_nranks = 1;
 hipStream_t g_comm_stream = nullptr;
+int g_comm_stream_device = -1;   // the device the stream and the slot events were created on
 constexpr int kSlots = 256;
 hipEvent_t g_done[kSlots] = {}, g_ready[kSlots] = {};   // per slot: "slice is final" (compute stream) / "all-reduce done" (comm stream)
 bool g_posted[kSlots] = {};
@@ -118,7 +119,20 @@ int convnet_hip_comm_init(int rank, int nranks, const char* id_in) {
   // process and kept across communicator lifetimes: every stream a process creates takes the next of GPU_MAX_HW_QUEUES hardware
   // queues, and a host that re-initialises the exchange (bench.py's strong-scaling leg after its weak run) got a comm stream that
   // shared a queue with its compute streams — 12.6 ms per step instead of 10.6 with a world of one.
+  // (... per DEVICE: a host that moved to another GPU between communicators — cuda_set_device — gets a stream and events of its own there)
+  int dev = 0;
+  CHIP_CHECK(hipGetDevice(&dev));
+  if (g_comm_stream && dev != g_comm_stream_device) {
+    hipStreamSynchronize(g_comm_stream);
+    hipStreamDestroy(g_comm_stream);
+    for (int i = 0; i < kSlots; ++i) {
+      hipEventDestroy(g_done[i]);
+      hipEventDestroy(g_ready[i]);
+    }
+    g_comm_stream = nullptr;
+  }
   if (!g_comm_stream) {
+    g_comm_stream_device = dev;
     CHIP_CHECK(hipStreamCreateWithFlags(&g_comm_stream, hipStreamNonBlocking));
     for (int i = 0; i < kSlots; ++i) {
       CHIP_CHECK(hipEventCreateWithFlags(&g_done[i], hipEventDisableTiming));

@@ -1544,6 +1544,7 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
   // the best estimated time = rounds * (work per block) + slab-reduce traffic; needs a launch that owns
   // the whole destination (dst_elems > 0).
   int splits = 1;
+  int tail_s_instead = 0;   // > 0: split-K was cancelled in favour of a tail split with this many K-ranges (the choice below must honour it)
   if (dst_elems > 0 && kchunks >= 16) {
     const double slots = slots_launch;
     const double flops = 2.0 * ROWS * (WC * (double)CW) * (double)p.K;           // per tile, all K
@@ -1567,6 +1568,7 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
         const double t = (full / slots + std::ceil(rem * (double)s / slots) / s) * t_round + rem * (s + 1.0) * tile_bytes / 4.0e12 + 6e-6;
         if (t < best_t) {
           splits = 1;
+          tail_s_instead = s;
           break;
         }
       }
@@ -1596,6 +1598,7 @@ void gg_launch_cfg(GGParams& p, bool vec, size_t dst_elems) {
         best_s = s;
       }
     }
+    if (best_s == 1 && tail_s_instead > 1) best_s = tail_s_instead;   // (the two estimates differ in form: never fall between them)
     if (best_s > 1) {
       p.tail_first = full;
       p.tail_cps = divup(kchunks, best_s);
@@ -1859,8 +1862,10 @@ inline bool gg_presplit_mode() {
 
 // k-row table of ggp_kernel's generic-k mode (GGParams::ktab), built once per geometry and kept on the device
 const unsigned* gk_table(int C, int H, int W, int N, int Ky, int Kx) {
-  static std::map<std::array<int, 6>, unsigned*> cache;
-  const std::array<int, 6> key = {C, H, W, N, Ky, Kx};
+  static std::map<std::array<int, 7>, unsigned*> cache;   // (keyed by device too: the table lives in that device's memory)
+  int dev = 0;
+  CHIP_CHECK(hipGetDevice(&dev));
+  const std::array<int, 7> key = {dev, C, H, W, N, Ky, Kx};
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   const int K = C * Ky * Kx, KP = divup(K, BK) * BK;
