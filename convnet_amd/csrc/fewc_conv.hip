@@ -15,7 +15,8 @@
 //   * blocks are persistent (one per CU, a contiguous run of tiles each); a fifth wave, the producer, refills the patch half by half
 //     for the NEXT tile while the four consumer waves work on this one (two barriers per tile) — its loads are the only vector-memory
 //     reads of the block, the consumers' only vector-memory instructions are stores;
-//   * the accumulators are double-buffered: while tile T accumulates, tile T-1's 48 stores per lane go out one per MFMA step.
+//   * the accumulators are double-buffered: while tile T accumulates, tile T-1 goes out between its MFMAs — as twelve 16-byte stores
+//     per lane after a 4 x 4 transpose inside each quad of lanes (the MFMA layout gives a lane one image and 16 rows).
 // k-slots: chunk c (of 10), k-group lh, slot j  <->  patch row r = 2c + (j >> 2)  (r = channel * 7 + tap row),  kx = 2 (j & 3) + lh.
 // kx == 7 does not exist: those 20 spare slots carry the 7 taps of patch row 20 (spare index s = 2c + (j >> 2) < 7: kx = s) and zeros
 // otherwise (filter planes zero, the source read points into a zeroed LDS region — no 0 x inf from a neighbour's pixel): 147 real
@@ -48,7 +49,7 @@ constexpr int ZERO_BYTES = 1024 + 256;        // a lane base spans < 1 024 bytes
 constexpr int LDS_BYTES = ZERO_OFF + ZERO_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 static_assert(A_BYTES % 1024 == 0, "filter bank in whole pieces");
-constexpr int NSTORE = 3 * 16;                // stores per lane and tile: one per accumulator register
+constexpr int NGROUP = 3 * 4;                 // 16-byte stores per lane and tile: one per four accumulator registers
 constexpr int DUMP_BYTES = 4096;              // where the stores of rows past F (and of the tile before the first) go
 
 // byte offset of patch row r inside the patch region
@@ -70,7 +71,7 @@ struct Params {
   int F, N, H, W, My, Mx, pady, padx;
   int XG, IB, tiles;
   int relu;
-  int diag;   // experiments (CONVNET_GFC_DIAG, -DCONVNET_DIAG builds): 1 = no write-out, 2 = no patch refill after the first tile
+  int diag;   // experiments (CONVNET_GFC_DIAG, -DCONVNET_DIAG builds): 1 = every store into the dump area, 2 = no patch refill after the first tile, 4 = no store instructions
 };
 
 }  // namespace gfc
@@ -184,7 +185,6 @@ __global__ __launch_bounds__(320, 1) void gfc_kernel(const gfc::Params p) {
   const unsigned base_l = (unsigned)(PATCH_OFF + (S * wave) * XB + li * 4 + lh * XB);
   const unsigned a_l = (unsigned)(A_OFF + (lh * ROWS + li) * 16);
   const unsigned lh_mask = lh ? 0xFFFFFFFFu : 0u;
-  const unsigned bias_l = (unsigned)(BIAS_OFF + 16 * lh);
 
   f32x16 acc[2][3];             // this tile's sums and the previous tile's, on their way out
   // filter fragments: the h plane of this chunk and the next (it is used up to the chunk's last product); the m and l planes are read for
@@ -238,6 +238,10 @@ __global__ __launch_bounds__(320, 1) void gfc_kernel(const gfc::Params p) {
     fb[s].h[q] = H;
     fb[s].m[q] = M;
     fb[s].l[q] = pk_bf16(s0, s1);
+    // "this pair is complete HERE" (its first use is a chunk away: unpinned, the optimizer sinks all four pairs to the end of the chunk)
+#ifndef CONVNET_EMU
+    asm volatile("" ::"v"(fb[s].h[q]), "v"(fb[s].m[q]), "v"(fb[s].l[q]));
+#endif
   };
   // product k over the three accumulators.  The six products of split_mac in an order that retires the l plane of the filter after
   // k = 1 and the m plane after k = 3: (h,l) (l,h) (m,m) (m,h) (h,m) (h,h) — small terms first, the leading one last, as there.
@@ -257,43 +261,83 @@ __global__ __launch_bounds__(320, 1) void gfc_kernel(const gfc::Params p) {
 #endif
   };
 
-  // ---- write-out of one tile: row f = 32 t + (reg & 3) + 8 (reg >> 2) + 4 lh, this wave's pixel, image li of the block.
-  // Address = a wave-uniform row base (scalar: the compile-time part of f) + the lane's 32-bit byte offset (pixel, image, 4 lh rows).
-  // Rows past F (F % 8 == 0, so that is the same for both lh) and a tile that does not exist (the one before the first, a pixel past
-  // the end of the image row) store into the dump area instead: no branch, the store always happens.
+  // ---- write-out of one tile, 16 bytes per lane.  The MFMA layout gives a lane ONE image (column li) and 16 rows per accumulator; four
+  // registers 4g .. 4g + 3 are four consecutive rows.  A 4 x 4 transpose inside each quad of lanes (two DPP butterfly stages, 16 VALU)
+  // turns them into four consecutive IMAGES of one row per lane: lane q = li & 3 of a quad ends up with row 32 t + 8 g + q + 4 lh, images
+  // 4 (li >> 2) .. + 3 — one global_store_dwordx4 per group instead of four dword stores (a vector-memory instruction costs a busy CU
+  // ~50-60 cycles whatever its width: 12 stores per lane and tile instead of 48).
+  // Address = a wave-uniform row base (scalar: 32 t + 8 g) + the lane's 32-bit byte offset (pixel, image quad, its q + 4 lh rows).
+  // Row groups past F (F % 8 == 0) and a tile that does not exist (the one before the first, a pixel past the end of the image row)
+  // store into the dump area instead: no branch, the store always happens.
   struct Out {
     unsigned lane_bytes;   // of the real destination
     int flim;              // rows below flim exist (0: nothing of this tile does)
   };
   const size_t fstride = (size_t)p.My * p.Mx * N;   // floats per output row
+  const int q4 = li & 3;
   auto out_of = [&](int xg_, int oy_, int ib_, bool exists) __attribute__((always_inline)) {
     const int ox = P * xg_ + wave;
     Out o;
-    o.lane_bytes = (unsigned)((((size_t)oy_ * p.Mx + ox) * N + ib_ * IMG + li + (size_t)(4 * lh) * fstride) * 4);
-    o.flim = exists && ox < p.Mx && !(p.diag & 1) ? p.F : 0;
+    o.lane_bytes = (unsigned)((((size_t)oy_ * p.Mx + ox) * N + ib_ * IMG + 4 * (li >> 2) + (size_t)(q4 + 4 * lh) * fstride) * 4);
+    o.flim = exists && ox < p.Mx ? p.F : 0;
+#ifdef CONVNET_DIAG
+    if (p.diag & 1) o.flim = 0;
+#endif
     return o;
   };
-  auto bias_of = [&](auto SS) __attribute__((always_inline)) {   // the bias of store SS's row, from LDS
-    constexpr int sidx = decltype(SS)::value, t = sidx >> 4, reg = sidx & 15;
-    constexpr int cf = 32 * t + (reg & 3) + 8 * (reg >> 2);
-    return *reinterpret_cast<const float*>(lds + bias_l + cf * 4);
+  const unsigned bias_q = (unsigned)(BIAS_OFF + (q4 + 4 * lh) * 4);
+  auto bias_of = [&](auto GG) __attribute__((always_inline)) {   // the bias of this lane's row in group GG = 4 t + g, from LDS
+    constexpr int gi = decltype(GG)::value;
+    return *reinterpret_cast<const float*>(lds + bias_q + (32 * (gi >> 2) + 8 * (gi & 3)) * 4);
   };
-  auto store_one = [&](auto SS, const Out& o, const f32x16 (&a)[3], float bias) __attribute__((always_inline)) {
-    constexpr int sidx = decltype(SS)::value, t = sidx >> 4, reg = sidx & 15;
-    constexpr int cf = 32 * t + (reg & 3) + 8 * (reg >> 2);
-    const bool real = (cf & ~7) < o.flim;                                             // wave-uniform
+  // lane-pair and lane-quad exchanges (quad_perm [1,0,3,2] and [2,3,0,1])
+  auto swap1 = [](float v) __attribute__((always_inline)) {
+#ifndef CONVNET_EMU
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+#else
+    return emu::shfl_xor(v, 1);
+#endif
+  };
+  auto swap2 = [](float v) __attribute__((always_inline)) {
+#ifndef CONVNET_EMU
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+#else
+    return emu::shfl_xor(v, 2);
+#endif
+  };
+  const bool odd1 = (li & 1) != 0, odd2 = (li & 2) != 0;
+  const bool no_relu = p.relu == 0;
+  auto store_group = [&](auto GG, const Out& o, const f32x16 (&a)[3], float bias) __attribute__((always_inline)) {
+    constexpr int gi = decltype(GG)::value, t = gi >> 2, g = gi & 3;
+    constexpr int cf = 32 * t + 8 * g;
+    // M[lane q][r] = a[t][4g + r]  ->  v[j] = M[j][q]
+    float x0 = a[t][4 * g], x1 = a[t][4 * g + 1], x2 = a[t][4 * g + 2], x3 = a[t][4 * g + 3];
+    {   // stage 1, partner lane ^ 1: (x0, x1) and (x2, x3)
+      const float r01 = swap1(odd1 ? x0 : x1), r23 = swap1(odd1 ? x2 : x3);
+      x0 = odd1 ? r01 : x0; x1 = odd1 ? x1 : r01;
+      x2 = odd1 ? r23 : x2; x3 = odd1 ? x3 : r23;
+    }
+    {   // stage 2, partner lane ^ 2: (x0, x1) <-> (x2, x3)
+      const float ra = swap2(odd2 ? x0 : x2), rb = swap2(odd2 ? x1 : x3);
+      x0 = odd2 ? ra : x0; x1 = odd2 ? rb : x1;
+      x2 = odd2 ? x2 : ra; x3 = odd2 ? x3 : rb;
+    }
+    f32x4 v = {x0 + bias, x1 + bias, x2 + bias, x3 + bias};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (no_relu | (v[e] > 0.f)) ? v[e] : 0.f;   // (a select: a branch here would cut the chunk's basic block)
+    const bool real = cf < o.flim;                                                     // wave-uniform
     char* const rowb = real ? reinterpret_cast<char*>(p.dst) + (size_t)cf * fstride * 4 : reinterpret_cast<char*>(p.dump);
-    const unsigned off = real ? o.lane_bytes : (unsigned)lane * 4u;
-    float* const dp = reinterpret_cast<float*>(rowb + off);
-    float v = a[t][reg] + bias;
-    if (p.relu) v = v > 0.f ? v : 0.f;
-    *dp = v;
+    const unsigned off = real ? o.lane_bytes : (unsigned)lane * 16u;
+#ifdef CONVNET_DIAG
+    if (p.diag & 4) return;   // (diag 4: the transposes without the store instruction)
+#endif
+    *reinterpret_cast<f32x4*>(rowb + off) = v;
   };
 
   // One chunk = six fenced steps of three MFMAs.  Step 0 carries the next chunk's source reads and its h plane (the m and l planes follow
   // in steps 4 and 2), steps 1-4 one pair each of its split
-  // (a pair is ~11 VALU: under four per MFMA), and steps 1-5 one store each of the PREVIOUS tile (5 x 10 >= 48) — with one consumer
-  // wave per SIMD nothing else hides them, and the stores drain at ~10 B/clk per CU however they are issued.
+  // (a pair is ~11 VALU: under four per MFMA), and step 5 (no split there) one 16-byte store group of the PREVIOUS tile — 12 groups over
+  // 10 chunks: the last two ride in step 0 of chunks 8 and 9 — with one consumer wave per SIMD nothing else hides them.
   auto chunk_body = [&](auto CC, bool has_next, f32x16 (&cur)[3], const f32x16 (&prev)[3], const Out& po) __attribute__((always_inline)) {
     constexpr int c = decltype(CC)::value, s = c & 1;
     using CN = std::integral_constant<int, (c + 1) % NCH>;
@@ -303,17 +347,17 @@ __global__ __launch_bounds__(320, 1) void gfc_kernel(const gfc::Params p) {
       read_a(CN{}, std::integral_constant<int, 0>{}, fah[s ^ 1]);
     }
     CHIP_HERE();
-    float bs[5];   // the bias values of this chunk's five stores, read with the operands: a read next to its use would wait on LDS
-    static_for<0, 5>([&](auto II) __attribute__((always_inline)) {
-      constexpr int i = decltype(II)::value;
-      if constexpr (5 * c + i < NSTORE) bs[i] = bias_of(std::integral_constant<int, 5 * c + i>{});
-    });
+    // the bias values of this chunk's store groups, read with the operands: a read next to its use would wait on LDS
+    const float bs0 = bias_of(std::integral_constant<int, c>{});
+    float bs1 = 0.f;
+    if constexpr (c >= 8) bs1 = bias_of(std::integral_constant<int, c + 2>{});
     static_for<0, 6>([&](auto KK) __attribute__((always_inline)) {
       constexpr int k = decltype(KK)::value;
       if constexpr (k >= 1 && k <= 4) {
         if (has_next) split_pair(s ^ 1, k - 1);
       }
-      if constexpr (k >= 1 && 5 * c + k - 1 < NSTORE) store_one(std::integral_constant<int, 5 * c + k - 1>{}, po, prev, bs[k - 1]);
+      if constexpr (k == 0 && c >= 8) store_group(std::integral_constant<int, c + 2>{}, po, prev, bs1);
+      if constexpr (k == 5) store_group(std::integral_constant<int, c>{}, po, prev, bs0);
       if constexpr (k == 2) {
         if (has_next) read_a(CN{}, std::integral_constant<int, 2>{}, fal);   // the l plane's last product (k = 1) has issued
       }
@@ -321,6 +365,15 @@ __global__ __launch_bounds__(320, 1) void gfc_kernel(const gfc::Params p) {
         if (has_next) read_a(CN{}, std::integral_constant<int, 1>{}, fam);   // the m plane's (k = 3)
       }
       mac_step(KK, s, cur);
+      // inside the step: an MFMA first, then a third of the step's other work behind each (the matrix pipe runs while the VALU / LDS
+      // instructions issue; left alone the scheduler puts the 35 VALU of a store group in FRONT of the step's MFMAs)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -357,14 +410,14 @@ __global__ __launch_bounds__(320, 1) void gfc_kernel(const gfc::Params p) {
     po = out_of(xg, oy, ib, true);
     next_tile();
     if (++T >= T1) {
-      static_for<0, NSTORE>([&](auto SS) __attribute__((always_inline)) { store_one(SS, po, acc[0], bias_of(SS)); });
+      static_for<0, NGROUP>([&](auto GG) __attribute__((always_inline)) { store_group(GG, po, acc[0], bias_of(GG)); });
       break;
     }
     run_tile(T + 1 < T1, acc[1], acc[0], po);
     po = out_of(xg, oy, ib, true);
     next_tile();
     if (++T >= T1) {
-      static_for<0, NSTORE>([&](auto SS) __attribute__((always_inline)) { store_one(SS, po, acc[1], bias_of(SS)); });
+      static_for<0, NGROUP>([&](auto GG) __attribute__((always_inline)) { store_group(GG, po, acc[1], bias_of(GG)); });
       break;
     }
   }
