@@ -66,7 +66,7 @@ def _same_kernel(bench_name, prof_name):
     if wb == "gpw_kernel":
         return "gpw_kernel(" in flat or flat.endswith("gpw_kernel") or "gpw_kernel<" in flat
     if wb == "gfc_kernel":   # "gfc_kernel<96x128,split>" is chip::gfc_kernel(chip::gfc::Params)
-        return "gfc_kernel(" in flat or flat.endswith("gfc_kernel")
+        return "gfc_kernel<" in flat or "gfc_kernel(" in flat or flat.endswith("gfc_kernel")   # gfc_kernel<RELU>
     if wb == "wgw_kernel":
         return ("wgw_kernel<3>" in flat and "256x192" in wa) or ("wgw_kernel<4>" in flat and "256x256" in wa)
     if wb == "gpp_kernel":

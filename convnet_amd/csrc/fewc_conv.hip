@@ -98,6 +98,9 @@ __global__ void gfc_planes_kernel(const float* __restrict__ W, u32x4* __restrict
   o[4 * ROWS] = sp.l;
 }
 
+// RELU: the fused ReLU of the write-out as a compile-time choice (one v_max per value; as a run-time flag it is a compare, a mask merge and a
+// select per value in a loop that is bound by instruction issue)
+template <bool RELU>
 __global__ __launch_bounds__(320, 1) void gfc_kernel(const gfc::Params p) {
   using namespace gfc;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -306,7 +309,6 @@ __global__ __launch_bounds__(320, 1) void gfc_kernel(const gfc::Params p) {
 #endif
   };
   const bool odd1 = (li & 1) != 0, odd2 = (li & 2) != 0;
-  const bool no_relu = p.relu == 0;
   auto store_group = [&](auto GG, const Out& o, const f32x16 (&a)[3], float bias) __attribute__((always_inline)) {
     constexpr int gi = decltype(GG)::value, t = gi >> 2, g = gi & 3;
     constexpr int cf = 32 * t + 8 * g;
@@ -323,8 +325,10 @@ __global__ __launch_bounds__(320, 1) void gfc_kernel(const gfc::Params p) {
       x2 = odd2 ? x2 : ra; x3 = odd2 ? x3 : rb;
     }
     f32x4 v = {x0 + bias, x1 + bias, x2 + bias, x3 + bias};
+    if constexpr (RELU) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (no_relu | (v[e] > 0.f)) ? v[e] : 0.f;   // (a select: a branch here would cut the chunk's basic block)
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);   // (NaN -> 0 like `v > 0 ? v : 0`; no branch: one would cut the chunk's basic block)
+    }
     const bool real = cf < o.flim;                                                     // wave-uniform
     char* const rowb = real ? reinterpret_cast<char*>(p.dst) + (size_t)cf * fstride * 4 : reinterpret_cast<char*>(p.dump);
     const unsigned off = real ? o.lane_bytes : (unsigned)lane * 16u;
@@ -436,7 +440,8 @@ bool gfc_try(const float* images, const float* filters, const float* bias, float
   static bool once = false;
   static int cus = 256;
   if (!once) {
-    CHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gfc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    CHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gfc_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    CHIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gfc_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
 #ifndef CONVNET_EMU
     int dev = 0;
     hipDeviceProp_t prop;
@@ -460,7 +465,8 @@ bool gfc_try(const float* images, const float* filters, const float* bias, float
   const int grid = std::min(cus, p.tiles);
   {
     KernelTimer timer("gfc_kernel<96x128,split>", "conv_fprop", flops, 0.0, 0.0);
-    hipLaunchKernelGGL(gfc_kernel, dim3(grid), dim3(320), LDS_BYTES, stream(), p);
+    if (relu) hipLaunchKernelGGL(gfc_kernel<true>, dim3(grid), dim3(320), LDS_BYTES, stream(), p);
+    else hipLaunchKernelGGL(gfc_kernel<false>, dim3(grid), dim3(320), LDS_BYTES, stream(), p);
   }
   note_kernel("gfc_kernel(fprop)", flops, grid, 1);
   return true;

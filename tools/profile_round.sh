@@ -13,16 +13,18 @@ echo "== bench (default flags: what the driver runs)"
 timeout 500 python bench.py > "$O/bench_n1.json" 2> "$O/bench_n1.err"; echo "rc=$?"; cut -c1-230 "$O/bench_n1.json"
 echo "== one-stream bench"
 timeout 200 python bench.py --no-overlap-wgrad --no-side-stream-update $Q > "$O/bench_n1_one_stream.json" 2>/dev/null; cut -c60-160 "$O/bench_n1_one_stream.json"
-echo "== same-call A/B against the previous round's library (convnet_amd/lib/libconvnet_hip_r03.so, tools/build_prev_lib.sh), where it is present"
-if [ -f convnet_amd/lib/libconvnet_hip_r03.so ]; then
+echo "== same-call A/B against the previous round's library (convnet_amd/lib/libconvnet_hip_r04.so, tools/build_prev_lib.sh), where it is present"
+if [ -f convnet_amd/lib/libconvnet_hip_r04.so ]; then
   for i in 1 2; do
-    CONVNET_HIP_LIB=libconvnet_hip_r03.so timeout 200 python bench.py $Q > "$O/bench_n1_r03lib_run$i.json" 2>/dev/null; echo "r03 lib: $(cut -c60-175 "$O/bench_n1_r03lib_run$i.json")"
+    CONVNET_HIP_LIB=libconvnet_hip_r04.so timeout 200 python bench.py $Q > "$O/bench_n1_r04lib_run$i.json" 2>/dev/null; echo "r04 lib: $(cut -c60-175 "$O/bench_n1_r04lib_run$i.json")"
     timeout 200 python bench.py $Q > "$O/bench_n1_now_run$i.json" 2>/dev/null; echo "now    : $(cut -c60-175 "$O/bench_n1_now_run$i.json")"
   done
-  CONVNET_HIP_LIB=libconvnet_hip_r03.so timeout 120 python tools/layer_bench.py > "$O/layer_bench_r03lib.txt" 2>&1
+  CONVNET_HIP_LIB=libconvnet_hip_r04.so timeout 120 python tools/layer_bench.py > "$O/layer_bench_r04lib.txt" 2>&1
 fi
-echo "== gather-GEMM kernel choices of this round, same call: ggp_kernel (0, default) / gpp_kernel raw (1) / gpp_kernel planes (2)"
-for m in 0 1 2; do CONVNET_GG_PATCH=$m timeout 120 python tools/layer_bench.py --only conv > "$O/layer_bench_patch$m.txt" 2>&1; grep -h "conv4.*fprop.*g.p_kernel\|conv4.*planes" "$O/layer_bench_patch$m.txt"; done
+echo "== kernel choices of this round, same call: round-4 kernels (patch 0, wgrad tile 0, no gfc) against the defaults"
+CONVNET_GG_PATCH=0 CONVNET_WG_TILE=0 CONVNET_GG_FEWC=0 timeout 120 python tools/layer_bench.py --only conv > "$O/layer_bench_r04_kernels.txt" 2>&1
+grep -h "conv[1-5].*_kernel<" "$O/layer_bench_r04_kernels.txt" | grep -v "planes\|reduce\|tail_fix" | head -20
+for v in "0 0 0" "3 1 1"; do set -- $v; CONVNET_GG_PATCH=$1 CONVNET_WG_TILE=$2 CONVNET_GG_FEWC=$3 timeout 200 python bench.py --steps 20 --warmup 5 $Q > "$O/bench_kernels_p$1_w$2_f$3.json" 2>/dev/null; echo "patch=$1 wgrad_tile=$2 fewc=$3: $(cut -c60-175 "$O/bench_kernels_p$1_w$2_f$3.json")"; done
 echo "== per-layer table"
 timeout 120 python tools/layer_bench.py > "$O/layer_bench.txt" 2>&1; grep -v amdgpu "$O/layer_bench.txt" | head -60
 timeout 120 python tools/pool_bench.py > "$O/pool_bench.txt" 2>&1
