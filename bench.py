@@ -125,7 +125,7 @@ def live_pmc_traffic(kernel, args):
     child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--batch", str(args.batch), "--model", args.model,
              "--matrix-path", args.matrix_path, "--no-cpu-baseline", "--no-ref-host", "--no-other-path", "--no-kernel-timers", "--no-live-traffic"]
     child += (["--unfused"] if args.unfused else []) + (["--no-overlap-wgrad"] if args.no_overlap_wgrad else []) + \
-             (["--no-side-stream-update"] if args.no_side_stream_update else [])
+             (["--side-stream-update"] if args.side_stream_update and not args.no_side_stream_update else [])
     sums = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -313,9 +313,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--model", default="alexnet", choices=["alexnet", "alexnet_nin", "mnist_conv", "lenet5", "vgg"])
-    ap.add_argument("--no-side-stream-update", action="store_true",
-                    help="serial UpdateWeights after Bprop instead of each edge's optimizer step on the second stream as soon as its "
-                         "gradient is final (bit-identical either way; measured with --overlap-wgrad: 11.23 -> 11.08 ms/step)")
+    ap.add_argument("--side-stream-update", action="store_true",
+                    help="every edge's optimizer step on the second stream as soon as its gradient is final, instead of on the main stream "
+                         "behind the backward pass (bit-identical either way).  Was the default through round 4 (11.23 -> 11.08 ms then); "
+                         "with round 5's kernels, which own their CUs, it costs 0.2 ms (9.46 vs 9.65 ms, profiles/r05_stream_configs.txt): off")
+    ap.add_argument("--no-side-stream-update", action="store_true", help="(the default now; accepted for older command lines)")
     ap.add_argument("--no-overlap-wgrad", action="store_true",
                     help="every edge's weight gradient on the main stream instead of on a second stream beside the rest of the backward "
                          "pass (bit-identical either way; measured 11.47 -> 11.23 ms/step)")
@@ -398,7 +400,7 @@ def main():
 
     text = getattr(models, args.model)()
     net = ConvNet(text, fused=not args.unfused, process_id=rank, num_processes=world, exchange=exchange,
-                  overlap_update=not args.no_side_stream_update, overlap_wgrad=not args.no_overlap_wgrad)
+                  overlap_update=args.side_stream_update and not args.no_side_stream_update, overlap_wgrad=not args.no_overlap_wgrad)
     net.SetBatchsize(args.batch)
     if args.staged_input:
         # the reference's real input path: a GPU-resident chunk of 256x256 images, per-batch random 224 crop + flip +
@@ -470,7 +472,8 @@ def main():
     # event (and rocprofv3) duration includes what its neighbour took.  Four more steps on ONE stream, every launch timed, give the
     # dominant kernel's undisturbed rate beside the one measured in the timed region (every rank runs them: collectives inside).
     prof_one_stream, dt_one_stream = None, None
-    if not (args.no_overlap_wgrad and args.no_side_stream_update) and not args.no_kernel_timers:
+    side_update = args.side_stream_update and not args.no_side_stream_update
+    if (not args.no_overlap_wgrad or side_update) and not args.no_kernel_timers:
         keep = (net.overlap_wgrad_, net.overlap_update_)
         net.overlap_wgrad_, net.overlap_update_ = False, False
         net.TrainOneBatch()
@@ -522,7 +525,7 @@ def main():
         for label in ("compute_only", "with_exchange"):
             ex2 = GradientExchange(bucket_bytes=int(args.bucket_mb * (1 << 20)), overlap=not args.no_overlap, transport=args.transport) if label == "with_exchange" else None
             n2 = ConvNet(text, fused=not args.unfused, process_id=rank, num_processes=world, exchange=ex2,
-                         overlap_update=not args.no_side_stream_update, overlap_wgrad=not args.no_overlap_wgrad)
+                         overlap_update=args.side_stream_update and not args.no_side_stream_update, overlap_wgrad=not args.no_overlap_wgrad)
             n2.SetBatchsize(sb)
             n2.SetupDataset(SyntheticDataHandler(n2, sb, seed=2000 + rank, num_batches=2))
             n2.AllocateMemory(False)
@@ -646,8 +649,8 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" + ("" if world == 1 else (" rccl-allreduce " + ("overlapped" if not args.no_overlap else "serial") + (" (C-ABI entries)" if args.transport == "abi" else "")))
                                       + (f" strong (global batch {args.global_batch} = {args.batch}/GPU)" if strong else f" weak ({args.batch}/GPU)"),
-                       "streams": ("weight gradients" if not args.no_overlap_wgrad else "") + (" + optimizer steps" if not args.no_side_stream_update else "") +
-                                  (" on a second HIP stream beside the backward pass" if not (args.no_overlap_wgrad and args.no_side_stream_update) else "one stream"),
+                       "streams": ("weight gradients" if not args.no_overlap_wgrad else "") + (" + optimizer steps" if (args.side_stream_update and not args.no_side_stream_update) else "") +
+                                  (" on a second HIP stream beside the backward pass" if (not args.no_overlap_wgrad or (args.side_stream_update and not args.no_side_stream_update)) else "one stream"),
                        "params": net.NumParameters(), "train_gflop_per_image": round(2e-9 * train_macs, 4)},
             "roofline": roofline,
         }
