@@ -376,7 +376,7 @@ void wgw_launch(WGParams& p, const char* op, double flops, double exec) {
 bool wgw_try(WGParams& p, bool vec, bool split_products, const char* op, double flops, double exec) {
   if (!wgrad_tile() || !vec || !split_products) return false;
   if (p.N % WG_NB != 0 || p.K < 256 || p.F < 192) return false;
-  if (p.chunks_total < 64) return false;   // an FC weight gradient: a handful of chunks per 256 x 256 outputs, write-out-bound either way
+  if (p.chunks_total < CHIP_DIAG_KNOB("CONVNET_WGW_MIN_CHUNKS", 64)) return false;   // an FC weight gradient: a handful of chunks per 256 x 256 outputs, write-out-bound either way
   const int pad256 = divup(p.F, 256) * 256, pad192 = divup(p.F, 192) * 192;
   if (pad192 < pad256) wgw_launch<3>(p, op, flops, exec);
   else wgw_launch<4>(p, op, flops, exec);
