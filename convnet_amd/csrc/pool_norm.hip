@@ -795,7 +795,7 @@ void ResponseNormCrossMapUndoGemm(cudamat* outGrads, cudamat* inputs, cudamat* t
       const size_t smem = sizeof(float) * 3 * (size_t)C * LT;
       const bool xcd = !CHIP_DIAG_KNOB("CONVNET_RNORM_NO_XCD", 0);   // A/B switch for the XCD-contiguous tile order
       const unsigned tiles = (unsigned)((locs + LT - 1) / LT);
-      const dim3 grid(xcd ? (tiles + 7) / 8 * 8 : tiles), block(256);
+      const dim3 grid(xcd ? (tiles + 7) / 8 * 8 : tiles), block(CHIP_DIAG_KNOB("CONVNET_RNORM_UNDO_THREADS", C > 128 ? 512 : 256));   // (rnorm2, C = 256: 75 -> 58 us with 8 instead of 16 channels per thread; C = 96: no difference)
       CHIP_REQUIRE(smem <= 160 * 1024);
 #define RN_UNDO(L)                                                                                                              \
   do {                                                                                                                          \
