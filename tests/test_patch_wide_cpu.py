@@ -225,7 +225,7 @@ DGRAD = [
 _id = lambda g: f"N{g.N}C{g.C}H{g.H}W{g.W}F{g.F}k{g.Ky}x{g.Kx}p{g.pady}"  # noqa: E731
 
 
-@pytest.mark.parametrize("sta", [3, 2], ids=["ring3", "ring2"])
+@pytest.mark.parametrize("sta", [3], ids=["ring3"])
 @pytest.mark.parametrize("lazy", [False, True], ids=["eager", "lazy"])
 @pytest.mark.parametrize("g", FPROP, ids=_id)
 def test_wide_tile_schedule_fprop(g, lazy, sta):
@@ -238,7 +238,7 @@ def test_wide_tile_schedule_fprop(g, lazy, sta):
     assert np.abs(got - ref).max() < 2e-4 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("sta", [3, 2], ids=["ring3", "ring2"])
+@pytest.mark.parametrize("sta", [3], ids=["ring3"])
 @pytest.mark.parametrize("lazy", [False, True], ids=["eager", "lazy"])
 @pytest.mark.parametrize("g", DGRAD, ids=_id)
 def test_wide_tile_schedule_dgrad(g, lazy, sta):

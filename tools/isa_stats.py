@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Static numbers of the main loops of gpw_kernel / wgw_kernel (the two kernels written after the round's last hardware run): compiles
+"""Static numbers of the main loops of gpw_kernel / wgw_kernel / gfc_kernel (the hand-scheduled one-block-per-CU kernels): compiles
 the translation units for gfx950 with the library's flags (-save-temps), finds each kernel's inner loop in the assembly and counts
 what one chunk issues — MFMAs, everything else per MFMA gap, branches, scratch accesses, LDS-DMA loads, LDS reads — plus the register
 and scratch figures of the kernel descriptor.  No GPU.  Usage: python tools/isa_stats.py > profiles/rNN_isa_wide_kernels.txt"""
@@ -14,13 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from convnet_amd import build as B  # noqa: E402
 
-KERNELS = {"patch_gemm.hip": [("gpw_kernel<0> (one staging load per step)", "_ZN4chip10gpw_kernelILi0EEEvNS_8GGParamsENS_12GGClassTableE", 96),
-                              ("gpw_kernel<1> (grouped staging loads)", "_ZN4chip10gpw_kernelILi1EEEvNS_8GGParamsENS_12GGClassTableE", 96),
-                              ("gpw_kernel<2> (two-stage filter ring)", "_ZN4chip10gpw_kernelILi2EEEvNS_8GGParamsENS_12GGClassTableE", 96)],
-           "wgrad_wide.hip": [("wgw_kernel<3, 0> (256 x 192, staging loads first)", "_ZN4chip10wgw_kernelILi3ELi0EEEvNS_8WGParamsE", 144),
-                              ("wgw_kernel<4, 0> (256 x 256, staging loads first)", "_ZN4chip10wgw_kernelILi4ELi0EEEvNS_8WGParamsE", 192),
-                              ("wgw_kernel<3, 1> (256 x 192, staging loads spread)", "_ZN4chip10wgw_kernelILi3ELi1EEEvNS_8WGParamsE", 144),
-                              ("wgw_kernel<4, 1> (256 x 256, staging loads spread)", "_ZN4chip10wgw_kernelILi4ELi1EEEvNS_8WGParamsE", 192)]}
+KERNELS = {"patch_gemm.hip": [("gpw_kernel (128 x 512 patch tile)", "_ZN4chip10gpw_kernelENS_8GGParamsENS_12GGClassTableE", 96)],
+           "wgrad_wide.hip": [("wgw_kernel<3> (256 x 192)", "_ZN4chip10wgw_kernelILi3EEEvNS_8WGParamsE", 144),
+                              ("wgw_kernel<4> (256 x 256)", "_ZN4chip10wgw_kernelILi4EEEvNS_8WGParamsE", 192)],
+           "fewc_conv.hip": [("gfc_kernel<true> (conv1 fprop, fused ReLU)", "_ZN4chip10gfc_kernelILb1EEEvNS_3gfc6ParamsE", 18)]}
 
 
 def instr(lines):
@@ -44,16 +41,20 @@ def main():
                 body = L[a:e]
                 # the hot loop: the back-branch whose span holds the most MFMAs
                 labels = {l.split(":")[0]: i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
-                best = None
+                best, loose = None, None
                 for i, l in enumerate(body):
                     m = re.match(r"\s*s_cbranch_\w+\s+(\.LBB\d+_\d+)", l) or re.match(r"\s*s_branch\s+(\.LBB\d+_\d+)", l)
                     if m and m.group(1) in labels and labels[m.group(1)] < i:
                         span = body[labels[m.group(1)]:i]
                         n = sum(1 for x in span if x.strip().startswith("v_mfma"))
                         if any(re.match(r"\s*s_(c)?branch", x) for x in span):
+                            if n > 0 and (loose is None or n > loose[2]):
+                                loose = (labels[m.group(1)], i, n)   # a loop with branches inside (gfc_kernel: two tiles per turn, the last-tile checks)
                             continue   # not the innermost loop
                         if best is None or n > best[2]:
                             best = (labels[m.group(1)], i, n)
+                if best is None or best[2] == 0:
+                    best = loose
                 lo, hi, nm = best
                 ops = list(instr(body[lo:hi + 1]))
                 cnt = collections.Counter(ops)

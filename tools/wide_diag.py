@@ -1,4 +1,4 @@
-"""Where does gpw_kernel (patch modes 3-5) differ from the default gather kernel?  Runs each geometry on both and prints the
+"""Where does gpw_kernel (patch mode 4: without its launch policy) differ from the default gather kernel?  Runs each geometry on both and prints the
 structure of the mismatch (which rows, pixels, images).  GPU only; no oracle involved (the default kernel is the reference here,
 it is parity-green against the oracle).  python tools/wide_diag.py [fprop|dgrad] [mode ...]"""
 import ctypes
@@ -70,7 +70,7 @@ def describe(name, got, ref):
 
 
 which = sys.argv[1] if len(sys.argv) > 1 else "fprop"
-modes = [int(a) for a in sys.argv[2:]] or [3]
+modes = [int(a) for a in sys.argv[2:]] or [4]
 rng = np.random.default_rng(5)
 for g in CASES:
     print(f"N{g.N} C{g.C} H{g.H}x{g.W} F{g.F} k{g.Ky} p{g.pady}:", flush=True)
