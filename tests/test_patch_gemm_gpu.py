@@ -224,3 +224,26 @@ def test_wide_launch_policy(hip):
             assert last_kernel() == ("gpw_kernel(dgrad)" if wide_expected else "gg_kernel(dgrad)"), (g, last_kernel())
         if ref is not None:
             assert rel_err(got, ref) < TOL
+
+
+def test_wide_tail_split_on_hardware(hip):
+    """More tiles than CUs and a partial last round: gpw_kernel cuts only the last round's tiles in K and gpw_tail_fix_kernel sums
+    their partial tiles (VGG-size layers take this path; the emulation covered it, tests/test_emulated_kernels.py).  1 058 tiles on 256
+    CUs: four whole rounds and 34 tail tiles; the reference is the default gather kernel on the same data (oracle-checked itself; the
+    layer is 80 GFLOP)."""
+    from convnet_amd import _lib
+    g = Geom(N=64, C=64, H=92, W=92, F=128, Ky=3, Kx=3, pady=1, padx=1)
+    rng = np.random.default_rng(35)
+    x, w = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape())
+    outs = []
+    for mode in (0, 3):
+        _lib.lib.convnet_hip_set_patch_mode(mode)
+        _lib.profile_enable(True)
+        outs.append(hip.conv_up(g, x, w))
+        names = [r["kernel"] for r in _lib.profile_report()]
+        _lib.profile_enable(False)
+        if mode == 3:   # (the launch policy takes it: one K-range, many rounds)
+            assert last_kernel() == "gpw_kernel(fprop)" and any(n.startswith("gpw_kernel") for n in names), (last_kernel(), names)
+            assert any(n == "gg_tail_fix_kernel" for n in names), names
+    _lib.lib.convnet_hip_set_patch_mode(DEFAULT_MODE)
+    assert rel_err(outs[1], outs[0]) < 1e-5

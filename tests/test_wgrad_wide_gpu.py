@@ -117,3 +117,31 @@ def test_wide_agrees_with_wg_kernel(hip):
         outs.append(hip.conv_outp(g, x, dy))
     _lib.lib.convnet_hip_set_wgrad_tile(1)
     assert rel_err(outs[1], outs[0]) < 1e-5   # same operand splits and products; the split-K partition differs
+
+
+def test_wide_single_block_epilogue_on_hardware(hip, wide):
+    """>= 256 tiles: one block per tile, no slabs — scaleTargets / scaleOutput and the bias row in the kernel's OWN write-out (the AlexNet
+    layers never get there: their 10-28 tiles are cut in K; the emulation covered this path, tests/test_emulated_kernels.py).  A layer
+    that size is beyond the CPU oracle's reach, so the reference here is wg_kernel on the same data (itself oracle-checked): same operand
+    splits and products, another partition of the reduction."""
+    from convnet_amd import _lib
+    from hip_adapter import conv_outp_bias
+    g = Geom(N=32, C=500, H=8, W=8, F=4096, Ky=3, Kx=3, pady=1, padx=1)   # K = 4500: 18 k-tiles (a spare row for the bias) x 16 filter tiles = 288
+    rng = np.random.default_rng(45)
+    x, dy = rnd(rng, g.in_shape()), rnd(rng, g.out_shape())
+    dw0, db0 = rnd(rng, g.filt_shape()), rnd(rng, (g.F,))
+    outs = []
+    for mode in (0, 1):
+        _lib.lib.convnet_hip_set_wgrad_tile(mode)
+        _lib.profile_enable(True)
+        dw, db = conv_outp_bias(g, x, dy, dw0.copy(), db0.copy(), 1.0, 0.5)
+        names = last_kernel_timer_names()
+        _lib.profile_enable(False)
+        assert any(n.startswith("wgw_kernel" if mode else "wg_kernel") for n in names), names
+        if mode:
+            assert not any("reduce" in n for n in names), names   # one block per tile: nothing to reduce
+        outs.append((dw, db))
+    _lib.lib.convnet_hip_set_wgrad_tile(1)
+    assert rel_err(outs[1][0], outs[0][0]) < 1e-5 and rel_err(outs[1][1], outs[0][1]) < 1e-5
+    ref_db = db0 + 0.5 * dy.reshape(g.F, -1).astype(np.float64).sum(axis=1)
+    assert rel_err(outs[1][1], ref_db.astype(np.float32)) < TOL
