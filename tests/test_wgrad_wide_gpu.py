@@ -58,6 +58,7 @@ CASES = [
     Geom(N=32, C=64, H=11, W=11, F=200, Ky=3, Kx=3),                           # ragged filter tile (200 of 256), no padding, 81 chunks
     Geom(N=96, C=16, H=12, W=12, F=224, Ky=5, Kx=5, sy=2, sx=2, pady=2, padx=2),  # stride 2, 5 x 5 taps, three chunks per pixel
     Geom(N=32, C=29, H=8, W=8, F=192, Ky=3, Kx=3, pady=1, padx=1),             # K = 261: five rows in the second k tile, spare row for the bias
+    Geom(N=32, C=32, H=9, W=9, F=198, Ky=3, Kx=3, pady=1, padx=1),             # F % 4 != 0: the direct 4-byte write-out
     Geom(N=256, C=256, H=13, W=13, F=384, Ky=3, Kx=3, pady=1, padx=1),         # conv3 itself: 9 x 2 tiles of 256 x 192
     Geom(N=256, C=384, H=13, W=13, F=256, Ky=3, Kx=3),                         # conv5 itself: 14 tiles of 256 x 256
 ]
@@ -79,7 +80,7 @@ def test_wide_wgrad_vs_oracle(hip, wide, g):
         assert rel_err(got, oracle.port.conv_outp(g, x, dy, t0.copy(), st, so)) < TOL
 
 
-@pytest.mark.parametrize("g", CASES[:5], ids=_id)
+@pytest.mark.parametrize("g", CASES[:6], ids=_id)
 def test_wide_wgrad_with_bias_row(hip, wide, g):
     from hip_adapter import conv_outp_bias
     rng = np.random.default_rng(42)
