@@ -195,6 +195,51 @@ __global__ void __launch_bounds__(256) pool_fwd_fixed_kernel(const float* __rest
   *reinterpret_cast<f32x4*>(op) = res;
 }
 
+// 3 x 3 stride-2 max pooling on 2 x 2 OUTPUT blocks: the four windows of a block cover 5 x 5 inputs, 25 loads for four outputs instead
+// of 36 (the per-output kernel above; the vector-memory path, not HBM, is what a pooling kernel saturates first — the same trade as
+// pool_undo_max32_block_kernel).  A maximum is a selection: same bits whatever the visiting order.
+__global__ void __launch_bounds__(256) pool_fwd_max32_block_kernel(const float* __restrict__ in, float* __restrict__ out, PoolGeo g, float st, float so) {
+  int bx, by, c;
+  if (!pool_block(g, bx, by, c)) return;
+  const int MB = (g.Mx + 1) >> 1;
+  const int j = bx * 256 + threadIdx.x;
+  if (j >= MB * g.nvec) return;
+  const int xb = j / g.nvec, n = 4 * (j - xb * g.nvec);
+  const int oy0 = 2 * by, ox0 = 2 * xb;
+  const int ys = oy0 * 2 + g.py, xs = ox0 * 2 + g.px;
+  const float* plane = in + (size_t)c * g.H * g.W * g.N + n;
+  f32x4 v[5][5];
+  bool ok[5][5];
+#pragma unroll
+  for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) {
+      const int y = ys + dy, x = xs + dx;
+      ok[dy][dx] = y >= 0 && y < g.H && x >= 0 && x < g.W;
+      const size_t o = ok[dy][dx] ? ((size_t)y * g.W + x) * g.N : 0;
+      v[dy][dx] = *reinterpret_cast<const f32x4*>(plane + o);
+    }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int oy = oy0 + a, ox = ox0 + b;
+      if (oy >= g.My || ox >= g.Mx) continue;
+      f32x4 acc = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[e] = (ok[2 * a + dy][2 * b + dx] && acc[e] < v[2 * a + dy][2 * b + dx][e]) ? v[2 * a + dy][2 * b + dx][e] : acc[e];
+      float* op = out + ((size_t)(c * g.My + oy) * g.Mx + ox) * g.N + n;
+      f32x4 res = so * acc;
+      if (st != 0.f) res = st * *reinterpret_cast<const f32x4*>(op) + res;
+      *reinterpret_cast<f32x4*>(op) = res;
+    }
+}
+
 template <bool MAX, int K, int S>
 __global__ void __launch_bounds__(256) pool_undo_fixed_kernel(const float* __restrict__ images, const float* __restrict__ grads,
                                                               const float* __restrict__ acts, float* __restrict__ out, PoolGeo g, float st,
@@ -641,7 +686,13 @@ void pool_fwd(cudamat* images, cudamat* targets, Shape4D* is, Shape4D* ts, const
   const int fx = fixed_window(g, vec);
   dim3 fgrid(divup(g.Mx * g.nvec, 256), g.My, g.C);
   if (fx) fgrid = pool_xcd_grid(g, fgrid.x, g.My, fgrid);
-  if (fx == 32)
+  if (fx == 32 && MAX && g.My * g.Mx >= 400 && CHIP_KNOB("CONVNET_POOL_FWD_BLOCK", 1)) {
+    // one thread per 2 x 2 output block: 25 loads for four outputs instead of 36 (small maps keep the per-output kernel's parallelism)
+    const int hb = (g.My + 1) / 2;
+    dim3 bgrid(divup(((g.Mx + 1) / 2) * g.nvec, 256), hb, g.C);
+    bgrid = pool_xcd_grid(g, bgrid.x, hb, bgrid);
+    hipLaunchKernelGGL(pool_fwd_max32_block_kernel, bgrid, dim3(256), 0, stream(), images->data_device, targets->data_device, g, st, so);
+  } else if (fx == 32)
     hipLaunchKernelGGL((pool_fwd_fixed_kernel<MAX, 3, 2>), fgrid, dim3(256), 0, stream(), images->data_device, targets->data_device, g, st, so);
   else if (fx == 22)
     hipLaunchKernelGGL((pool_fwd_fixed_kernel<MAX, 2, 2>), fgrid, dim3(256), 0, stream(), images->data_device, targets->data_device, g, st, so);

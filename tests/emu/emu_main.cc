@@ -412,6 +412,7 @@ int main(int argc, char** argv) {
       abi_dot_case(64, 256, 128);
       pool_case(32, 32, 21, 3, 2);        // pool1 type (3 x 3 stride 2; 441 pixels: the 2 x 2-block undo kernel)
       pool_case(64, 16, 7, 3, 2);         // a small map: the per-output undo kernel
+      pool_case(32, 8, 43, 3, 2);         // 21 x 21 outputs: the 2 x 2-block forward kernel with an odd last row and column
       rnorm_case(32, 96, 25, 5);          // rnorm1 type: 96 channels, window 5
       rnorm_case(16, 256, 9, 5);
       sgd_case(96, 147);
