@@ -191,6 +191,32 @@ __device__ __forceinline__ void lds_dma_piece_rfl(unsigned voff, const char* s, 
   if constexpr (J == 2) asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(voff), "s"(s), "s"(lds) : "memory", "m0");
   if constexpr (J == 3) asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(s), "s"(lds) : "memory", "m0");
 }
+// A QUARTER piece: lanes 0..15 only (256 bytes) — the tail of a 96-row filter chunk's per-wave share (9 216 B / 4 waves = 2 304 B = two
+// pieces and a quarter).  EXEC is narrowed around the one instruction and restored inside the statement.
+template <int J>
+__device__ __forceinline__ void lds_dma_quarter_rfl(unsigned voff, const char* s, unsigned lds) {
+  static_assert(J >= 0 && J < 4, "immediate offset");
+  unsigned long long keep;
+  if constexpr (J == 0) asm volatile("s_nop 4\n\ts_mov_b32 m0, %3\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xffff\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(keep) : "v"(voff), "s"(s), "s"(lds) : "memory", "m0");
+  if constexpr (J == 1) asm volatile("s_nop 4\n\ts_mov_b32 m0, %3\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xffff\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b64 exec, %0" : "=&s"(keep) : "v"(voff), "s"(s), "s"(lds) : "memory", "m0");
+  if constexpr (J == 2) asm volatile("s_nop 4\n\ts_mov_b32 m0, %3\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xffff\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b64 exec, %0" : "=&s"(keep) : "v"(voff), "s"(s), "s"(lds) : "memory", "m0");
+  if constexpr (J == 3) asm volatile("s_nop 4\n\ts_mov_b32 m0, %3\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xffff\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b64 exec, %0" : "=&s"(keep) : "v"(voff), "s"(s), "s"(lds) : "memory", "m0");
+}
+// A piece that exists only when the wave-uniform flag `on` is set, the scalar branch around it INSIDE the statement: written as
+// `if (on) piece` the compiler moved every loop iterator of gpv_kernel onto the vector ALU (+100 VALU per chunk); what it cannot see
+// it cannot restructure.  Likewise the closing wait whose count depends on the flag.
+template <int J>
+__device__ __forceinline__ void lds_dma_piece_if_rfl(int on, unsigned voff, const char* s, unsigned lds) {
+  static_assert(J >= 0 && J < 4, "immediate offset");
+  if constexpr (J == 0) asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 1f\n\ts_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n1:" ::"v"(voff), "s"(s), "s"(lds), "s"(on) : "memory", "m0", "scc");
+  if constexpr (J == 1) asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 1f\n\ts_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n1:" ::"v"(voff), "s"(s), "s"(lds), "s"(on) : "memory", "m0", "scc");
+  if constexpr (J == 2) asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 1f\n\ts_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048\n1:" ::"v"(voff), "s"(s), "s"(lds), "s"(on) : "memory", "m0", "scc");
+  if constexpr (J == 3) asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 1f\n\ts_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072\n1:" ::"v"(voff), "s"(s), "s"(lds), "s"(on) : "memory", "m0", "scc");
+}
+// s_waitcnt vmcnt(on ? 11 : 7) lgkmcnt(0)
+__device__ __forceinline__ void wait_vm_7_or_11(int on) {
+  asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)\n\ts_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(7)\n1:" ::"s"(on) : "memory", "scc");
+}
 __device__ __forceinline__ void lds_dma2(unsigned voff, const char* s0, const char* s1, unsigned lds) {
   asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
                "global_load_lds_dwordx4 %0, %1\n\t"
@@ -220,6 +246,15 @@ inline void lds_dma4_rfl(unsigned voff, const char* s0, const char* s1, const ch
 inline void lds_dma3_rfl(unsigned voff, const char* s0, const char* s1, const char* s2, unsigned lds) { lds_dma3(voff, s0, s1, s2, lds); }
 template <int J>
 inline void lds_dma_piece_rfl(unsigned voff, const char* s, unsigned lds) { emu_piece(voff, s, lds, J); }
+template <int J>
+inline void lds_dma_quarter_rfl(unsigned voff, const char* s, unsigned lds) {
+  if (emu::lane_id() < 16) emu_piece(voff, s, lds, J);
+}
+template <int J>
+inline void lds_dma_piece_if_rfl(int on, unsigned voff, const char* s, unsigned lds) {
+  if (on) emu_piece(voff, s, lds, J);
+}
+inline void wait_vm_7_or_11(int) {}
 inline void lds_dma2(unsigned voff, const char* s0, const char* s1, unsigned lds) { emu_piece(voff, s0, lds, 0); emu_piece(voff, s1, lds, 1); }
 inline void lds_dma1(unsigned voff, const char* s0, unsigned lds) { emu_piece(voff, s0, lds, 0); }
 inline void lds_store16(unsigned addr, u32x4 v) { std::memcpy(lds_ptr(addr), &v, 16); }
@@ -285,9 +320,9 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[MT]
   int m, n;
   if (p.patch) {
     // unit tile: wave-column wc holds CW/64 units, lane li the images NTC*li % 64 .. + NTC - 1 of unit (NTC*li)/64 of them
-    // units per tile: kPatchP (gpp_kernel), kWideP for gpw_kernel's <1, 4, 4, 128> — spelled so that every other instantiation keeps the
-    // constant (and the machine code) it was validated with
-    constexpr int PU = (WR == 1 && WC == 4 && MT == 4 && CW == 128) ? kWideP : kPatchP;
+    // units per tile: kPatchP (gpp_kernel), kWideP for gpw_kernel's <1, 4, 4, 128> and gpv_kernel's <1, 4, 3 | 4, 128> — spelled so that every
+    // other instantiation keeps the constant (and the machine code) it was validated with
+    constexpr int PU = (WR == 1 && WC == 4 && (MT == 4 || MT == 3) && CW == 128) ? kWideP : kPatchP;
     const int U = col_tile * PU + wc * (CW / 64) + (NTC * li) / 64;
     const int ib = U / pG;
     if (ib >= p.IB) return;
@@ -511,6 +546,9 @@ void filter_planes_rt_launch(const PatchBank& bank, void* out, int TYX, int TH, 
 void filter_planes_gk_launch(const float* W, void* out, int F, int K, int KP, int TH, const char* op);   // generic k order (conv1)
 bool patch_shape_ok(GGParams& p, size_t dst_elems);
 void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, const PatchBank& bank);
+// every stride class of a strided input gradient in one gpv_kernel launch (the classes' banks already as bf16 planes per row tile)
+bool patch_classes_ok(const GGParams& base, const GGClassTable& ct);
+void patch_run_classes(GGParams& p, GGClassTable& ct, const char* op, double flops, double exec);
 
 // gfc_kernel (fewc_conv.hip): conv fprop of a few-channel, wide-filter, stride-2 layer (AlexNet conv1) as a patch-resident gather-GEMM
 // with the filter bank resident in LDS; takes the launch and returns true where the shape is of that kind

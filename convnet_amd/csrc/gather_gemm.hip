@@ -2127,7 +2127,12 @@ static void conv_down_impl(cudamat* derivs, cudamat* filters, cudamat* targets, 
   if (multi && ct.n > 0) {
     t_flops = alg_flops;
     t_exec = flops;
-    gg_run_classes(base, ct, vec);
+    if (pre && patch_classes_ok(base, ct)) {
+      patch_run_classes(base, ct, t_op, t_flops, t_exec);   // the wide tile over 3- and 2-tap rows (patch_gemm.hip: gpv_kernel)
+      patched = true;
+    } else {
+      gg_run_classes(base, ct, vec);
+    }
     blocks = ct.c[ct.n - 1].tile_end;
   }
   note_kernel(!patched ? "gg_kernel(dgrad)" : convnet_hip_get_patch_mode() >= 3 ? "gpw_kernel(dgrad)" : "gpp_kernel(dgrad)", alg_flops, blocks, 1);

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(WR* WC * 64 + 64, 2) void gpp_kernel(const GGParams
   int nchunks;
   if (ng == 1) nchunks = nsc * gc0;
   else {
-    const int n1 = ((sc_end + 1) >> 1) - ((sc_beg + 1) >> 1);   // odd indices in [sc_beg, sc_end)
+    const int n1 = (sc_end >> 1) - (sc_beg >> 1);   // odd indices in [sc_beg, sc_end)
     nchunks = (nsc - n1) * gc0 + n1 * gc1;
   }
 
@@ -1086,12 +1086,12 @@ __global__ __launch_bounds__(256, 1) void gpw_kernel(const GGParams pin, const G
   gg_epilogue<1, WC, MT, CW, true, true>(p, acc, row_tile, col_tile, split, T.ncols, T.GX, T.G, T.dy0, T.dx0);
 }
 
-// gg_tail_fix_kernel for gpw_kernel's tile: the same four blocks per tail tile, each summing the tail_splits partial tiles of a quarter
-// of the accumulator registers in fixed order and running the normal epilogue on them — with the quarter a COMPILE-TIME constant per
+// gg_tail_fix_kernel for gpw_kernel's / gpv_kernel's tile: the same four blocks per tail tile, each summing the tail_splits partial tiles of a
+// quarter of the accumulator registers in fixed order and running the normal epilogue on them — with the quarter a COMPILE-TIME constant per
 // branch: with 256 accumulator registers per lane the runtime range of gg_tail_fix_kernel indexes the array dynamically (2 KB of scratch).
-template <int PART>
+template <int MT, int PART>
 __device__ __forceinline__ void gpw_tail_fix_part(const GGParams& p, int tile) {
-  constexpr int WC = 4, MT = 4, CW = 128, NT = WC * 64, NTC = CW / 32, ROWS = MT * 32;
+  constexpr int WC = 4, CW = 128, NT = WC * 64, NTC = CW / 32, ROWS = MT * 32;
   constexpr int reg_lo = PART * (16 / kTailFixParts), reg_hi = reg_lo + 16 / kTailFixParts;
   using fvec = __attribute__((ext_vector_type(NTC))) float;
   const int L = p.tail_first + tile;
@@ -1110,14 +1110,483 @@ __device__ __forceinline__ void gpw_tail_fix_part(const GGParams& p, int tile) {
     }
   gg_epilogue<1, WC, MT, CW, true>(p, acc, L % p.row_tiles, L / p.row_tiles, 0, p.ncols, p.GX, p.G, p.dy0, p.dx0, reg_lo, reg_hi);
 }
+template <int MT>
 __global__ __launch_bounds__(256) void gpw_tail_fix_kernel(const GGParams p) {
   const int tile = blockIdx.x / kTailFixParts;
   switch (blockIdx.x % kTailFixParts) {
-    case 0: gpw_tail_fix_part<0>(p, tile); break;
-    case 1: gpw_tail_fix_part<1>(p, tile); break;
-    case 2: gpw_tail_fix_part<2>(p, tile); break;
-    default: gpw_tail_fix_part<3>(p, tile); break;
+    case 0: gpw_tail_fix_part<MT, 0>(p, tile); break;
+    case 1: gpw_tail_fix_part<MT, 1>(p, tile); break;
+    case 2: gpw_tail_fix_part<MT, 2>(p, tile); break;
+    default: gpw_tail_fix_part<MT, 3>(p, tile); break;
   }
+}
+
+// gpv_kernel: gpw_kernel's tile and staging scheme for tap rows cut into GROUPS of three or two taps — what AlexNet's second layer needs:
+//   * its 5 x 5 stride-2 forward pass (the reference special-cases the same class, cudamat_conv_filteracts.cu:985-1140): a tap row is the
+//     groups {0,2,4} and {1,3}; inside a group neighbouring output pixels' taps coincide exactly as in a stride-1 row (slot i of pixel
+//     j+1 = slot i+1 of pixel j), so a group is a slab of 8 + cnt - 1 slots and a SUPERCHUNK of cnt chunks;
+//   * the four stride classes of its input gradient (cudamat_conv_imgacts.cu:355-392 is the reference's gather form), each a stride-1
+//     gather with 3- or 2-tap rows, all classes in ONE launch (GGClassTable, as ggp_kernel runs them), on an MT = 3 build: 96 rows.
+// Everything gpw_kernel's header says holds; what is new:
+//   * the superchunk walk is (16-channel block, tap row, group), the chunk count per superchunk 3 or 2 (runtime, wave-uniform);
+//   * a 3-chunk superchunk gives every wave one slot of the next slab per chunk (7 loads per chunk, as gpw_kernel); a 2-chunk superchunk
+//     must bring the next slab's first-needed slots (positions 0..7 of the order: what tap slot 0 reads) under way in its FIRST chunk,
+//     so that chunk carries TWO slots per wave (11 loads) and the second one (7).  The chunk body is a template over that count — the
+//     wait in front of the chunk barrier needs it as an immediate — and the loop picks the body with one scalar branch per chunk;
+//   * the slab buffers still alternate per superchunk; the first-needed order is computed over three tap slots whatever the group:
+//     a slot only tap slot 2 reads is "nobody's" in a 2-tap group (a dump load);
+//   * MT = 3: a filter chunk is 9 216 B, a wave's share two pieces and a quarter (lds_dma_quarter_rfl: 16 lanes).
+// Restated with adversarial load landing in tests/test_patch_var_cpu.py, run on the CPU by tests/test_emulated_kernels.py.
+template <int MT>
+__global__ __launch_bounds__(256, 1) void gpv_kernel(const GGParams pin, const GGClassTable ct) {
+  constexpr int WC = 4, CW = 128, NTC = CW / 32, P = kWideP, NS = kWideNS;
+  using fvec = __attribute__((ext_vector_type(NTC))) float;
+  constexpr int NC = WC * 64;
+  constexpr int ROWS = MT * 32;
+  constexpr int A_STAGE = 6 * ROWS * 4;   // floats: 3 planes x 2 k-groups x ROWS x 16 bytes
+  constexpr int STA = 3;                  // A ring: filter chunks staged two ahead
+  constexpr int SLAB = NS * 1024;         // floats per slab: a slot is 16 k-rows x 64 images of fp32
+  constexpr unsigned A_WAVE = A_STAGE * 4 / WC;   // bytes of a filter chunk per wave: 3 072 (MT = 4), 2 304 (MT = 3)
+  static_assert(MT == 4 || MT == 3, "a wave's share of a filter chunk is three pieces, or two and a quarter");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                   // [STA][A_STAGE]
+  float* Bs = smem + STA * A_STAGE;   // [2][SLAB], then a 4 KB dump slot
+
+  const GGParams& p = pin;
+  GGTile T;
+  if (!gg_select_tile(p, ct, T)) return;
+  const int L = T.L, tsplit = T.tsplit;
+  const int row_tile = L % p.row_tiles, col_tile = L / p.row_tiles;
+  const int split = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int N = p.N;
+  const int dir = p.dir, SH = p.SH, SW = p.SW, ssx = p.ssx;
+  auto sgpr = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+
+  // ---- tap groups of a tap row (patch_shape_ok's rule, from the tile's own TX: the stride classes differ in it) --------------------
+  //   group g: taps gb0[g] + i*dstep, i < cnt[g]; ng = ssx groups.  One group: both entries equal.
+  const int TX = sgpr(T.TX), TYX = sgpr(T.TYX), TYn = sgpr(TYX / TX);
+  const int ng = ssx;
+  const int cnt0 = sgpr(ssx == 1 ? TX : (TX + 1) >> 1), cnt1 = sgpr(ssx == 1 ? TX : TX >> 1);
+  const int gb00 = sgpr(dir > 0 ? 0 : (cnt0 - 1) * ssx), gb01 = sgpr(ssx == 1 ? gb00 : dir > 0 ? 1 : 1 + (cnt1 - 1) * ssx);
+  const int dstep = dir * ssx;
+
+  // ---- the tile's units (wave-uniform), reduced at once to what the loop needs: as gpw_kernel, plus per lane s < NS the smallest
+  //      tap slot that reads slot s (imin: a slot only tap slot 2 reads does not exist for a 2-tap group)
+  const int G = T.G, GX = T.GX, units = p.IB * G;
+  int ys_f = 1 << 30, ys_l = -(1 << 30);
+  int S_l = 0, my_ord[3] = {-1, -1, -1};
+  int sy_l = 0, sx_l = 0, sib_l = 0, imin_l = 3;
+  {
+    int S[P], oy[P], ox[P], ib[P];
+    bool ok[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int U = col_tile * P + j;
+      ok[j] = U < units;
+      ib[j] = ok[j] ? U / G : 0;
+      const int m = ok[j] ? U - ib[j] * G : 0;
+      oy[j] = m / GX;
+      ox[j] = m - oy[j] * GX;
+      if (ok[j]) {
+        const int ys0 = oy[j] * p.ssy + T.y0;
+        ys_f = min(ys_f, ys0);
+        ys_l = max(ys_l, ys0);
+      }
+      S[j] = j == 0 ? 0 : S[j - 1] + (!ok[j] ? 0 : (ib[j] == ib[j - 1] && oy[j] == oy[j - 1]) ? 1 : 3);
+    }
+    const int ju = wave * 2 + ((li >> 4) & 1), s = lane & 15;
+    unsigned seen = 0;
+    int no = 0;
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+      if (j == ju) S_l = S[j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int sl = S[j] + i;
+        if (ok[j] && sl < NS && !((seen >> sl) & 1)) {
+          seen |= 1u << sl;
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            if (no == 4 * q + wave) my_ord[q] = sl;
+          ++no;
+        }
+        if (ok[j] && sl == s) {
+          imin_l = min(imin_l, i);
+          sy_l = oy[j] * p.ssy + T.y0;
+          sx_l = ox[j] * ssx + T.x0 + dir * gb00 + i * ssx;   // group 0's source column; group 1's is dir*(gb01 - gb00) further
+          sib_l = ib[j] * 64;
+        }
+      }
+  }
+  // per group: does a unit read this lane's slot, and is its source column inside the image
+  const int sx1_l = sx_l + dir * (gb01 - gb00);
+  const bool valid0_l = imin_l < cnt0, valid1_l = imin_l < cnt1;
+  const bool xin0_l = valid0_l && (unsigned)sx_l < (unsigned)SW, xin1_l = valid1_l && (unsigned)sx1_l < (unsigned)SW;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) my_ord[q] = sgpr(my_ord[q]);
+  ys_f = sgpr(ys_f);
+  ys_l = sgpr(ys_l);
+
+  // ---- reduction range in superchunks (16-channel block cb, tap row a, group g); cnt[g] chunks (taps) each --------------------------
+  int a_lo = 0, a_hi = TYn - 1;
+  const bool skip = tsplit < 0 && p.splits == 1;
+  if (skip) {   // tap rows that exist for some pixel of the tile
+    if (dir > 0) { a_lo = max(0, -ys_l); a_hi = min(TYn - 1, SH - 1 - ys_f); }
+    else { a_lo = max(0, ys_f - (SH - 1)); a_hi = min(TYn - 1, ys_l); }
+  }
+  a_lo = sgpr(a_lo);
+  a_hi = sgpr(a_hi);
+  const int nrow = max(0, a_hi - a_lo + 1);
+  const int nsc_all = (p.KC / BK) * nrow * ng;
+  int sc_beg = 0, sc_end = nsc_all;
+  if (!skip) {
+    const int cps = tsplit >= 0 ? p.tail_cps : p.chunks_per_split;
+    sc_beg = min(nsc_all, (tsplit >= 0 ? tsplit : split) * cps);
+    sc_end = min(nsc_all, sc_beg + cps);
+  }
+  sc_beg = sgpr(sc_beg);   // (what comes out of an integer division lives in VGPRs although it is wave-uniform, and drags its users along)
+  sc_end = sgpr(sc_end);
+  const int n_g1 = ng == 2 ? (sc_end >> 1) - (sc_beg >> 1) : 0;   // superchunks of group 1 (odd indices) in the range
+  const int nchunks = (sc_end - sc_beg - n_g1) * cnt0 + n_g1 * cnt1;
+  // first superchunk: group, tap row - a_lo, channel block
+  const int g_beg = ng == 2 ? (sc_beg & 1) : 0;
+  const int rr = ng == 2 ? sc_beg >> 1 : sc_beg;
+  const int cb_beg = nrow > 0 ? sgpr(rr / nrow) : 0, r_beg = nrow > 0 ? sgpr(rr % nrow) : 0;
+
+  f32x16 acc[MT][NTC];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int u = 0; u < NTC; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+
+  if (nchunks > 0) {
+    // ================================ staging (every wave its share) ================================
+    const size_t ch_bytes = (size_t)SH * SW * N * 4;
+    const unsigned lane_off_raw = (unsigned)((size_t)(lane >> 4) * ch_bytes + (size_t)(lane & 15) * 16);
+    const char* const rawsrc = reinterpret_cast<const char*>(p.src);
+    const char* const zero_page = reinterpret_cast<const char*>(p.zero);
+    const unsigned a_lane = (unsigned)lane * 16u;
+    const char* const abase0 = reinterpret_cast<const char*>(T.A) + (size_t)row_tile * (6 * ROWS * 16) + A_WAVE * wave;
+    const size_t a_chunk_bytes = (size_t)p.row_tiles * (6 * ROWS * 16);
+    const unsigned lds_a = lds_addr(As) + A_WAVE * wave;
+    const unsigned lds_b = lds_addr(Bs);
+    const unsigned lds_dump = lds_b + 2u * SLAB * 4u;
+
+    // Everything below steps with selects between values that are already computed (gpw_kernel's rules: no lazily evaluated side, 0/1
+    // flags and masks instead of booleans, differences instead of selected addresses).
+    // filter iterator, two chunks ahead of the MFMAs: tap slot i of group g of tap row a of channel block cb is filter chunk
+    // cb*TYX + a*TX + gb0[g] + i*dstep; a running pointer and its byte steps: next tap; what a finished group adds on top (to the
+    // next group of the row, or from the last group to the first of the next row); what a finished channel block adds on top.
+    const ptrdiff_t a_tap = (ptrdiff_t)a_chunk_bytes * dstep;
+    const ptrdiff_t a_x0 = (ptrdiff_t)a_chunk_bytes * ((ng == 2 ? gb01 : TX + gb00) - (gb00 + (cnt0 - 1) * dstep) - dstep);
+    const ptrdiff_t a_x1 = ng == 2 ? (ptrdiff_t)a_chunk_bytes * (TX + gb00 - (gb01 + (cnt1 - 1) * dstep) - dstep) : a_x0;
+    const ptrdiff_t a_cbs_x = (ptrdiff_t)a_chunk_bytes * (TYX - (a_hi - a_lo + 1) * TX);
+    const char* a_ptr = abase0 + a_chunk_bytes * (size_t)(cb_beg * TYX + (a_lo + r_beg) * TX + (g_beg ? gb01 : gb00));   // wave-uniform
+    int A_i = 0, A_g = g_beg, A_cnt = g_beg ? cnt1 : cnt0, A_r = r_beg, A_left = nchunks;
+    unsigned lds_f0 = lds_a, lds_f1 = lds_a + A_STAGE * 4u, lds_f2 = lds_a + 2u * A_STAGE * 4u;   // the ring stage to fill next first
+    const char* a_cur = nullptr;
+    unsigned a_lds = 0;
+    auto issue_a_addr = [&]() __attribute__((always_inline)) {
+      a_cur = uniform_ptr(a_ptr);
+      a_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_f0);
+    };
+    auto issue_a_piece = [&](auto J) __attribute__((always_inline)) {
+      constexpr int j = decltype(J)::value;
+      if constexpr (MT == 3 && j == 2) lds_dma_quarter_rfl<j>(a_lane, a_cur, a_lds);
+      else lds_dma_piece_rfl<j>(a_lane, a_cur, a_lds);
+    };
+    auto issue_a_step = [&]() __attribute__((always_inline)) {
+      const unsigned f = lds_f0;
+      lds_f0 = lds_f1;
+      lds_f1 = lds_f2;
+      lds_f2 = f;
+      --A_left;
+      const int more = (int)((unsigned)(-A_left) >> 31);            // 1 while chunks are left
+      const int i1 = A_i + 1, w1 = 1 - (int)((unsigned)(i1 - A_cnt) >> 31);   // w1 = 1 when the group is complete
+      A_i = i1 & (w1 - 1);
+      const ptrdiff_t xg = a_x0 + (-(ptrdiff_t)A_g & (a_x1 - a_x0));           // what THIS group's end adds
+      const int g1 = A_g + w1, wg = 1 - (int)((unsigned)(g1 - ng) >> 31);      // wg = 1 when the tap row is complete
+      A_g = g1 - (ng & -wg);
+      A_cnt = cnt0 + ((cnt1 - cnt0) & -A_g);
+      const int r1 = A_r + wg, w2 = 1 - (int)((unsigned)(r1 - nrow) >> 31);    // w2 = 1 when the channel block is complete
+      A_r = r1 - (nrow & -w2);
+      const ptrdiff_t d = a_tap + (-(ptrdiff_t)w1 & xg) + (-(ptrdiff_t)w2 & a_cbs_x);
+      a_ptr += -(ptrdiff_t)more & d;
+    };
+    auto issue_a = [&]() __attribute__((always_inline)) {   // (prologue)
+      issue_a_addr();
+      issue_a_piece(std::integral_constant<int, 0>{});
+      issue_a_piece(std::integral_constant<int, 1>{});
+      issue_a_piece(std::integral_constant<int, 2>{});
+      issue_a_step();
+    };
+    // slab iterator, one superchunk ahead: group, tap row and the source pointer of its channel block
+    int B_g = g_beg, B_r = r_beg;
+    const size_t cb_bytes = 16 * ch_bytes;   // one 16-channel block of the source
+    const char* slab_src = rawsrc + (size_t)cb_beg * cb_bytes;
+    auto slab_next = [&](int step) __attribute__((always_inline)) {   // step: 0 / 1
+      const int g1 = B_g + step, wg = 1 - (int)((unsigned)(g1 - ng) >> 31);
+      B_g = g1 - (ng & -wg);
+      const int r1 = B_r + wg, w = 1 - (int)((unsigned)(r1 - nrow) >> 31);
+      B_r = r1 - (nrow & -w);
+      slab_src += -(ptrdiff_t)w & (ptrdiff_t)cb_bytes;
+    };
+    constexpr unsigned kNoSlot = 0xFFFFFFFFu;     // no unit of the tile reads this slot: the load goes to the dump region
+    constexpr unsigned kZeroSlot = 0xFFFFFFFEu;   // read, but outside the image: loaded from the zero page
+    auto slot_desc = [&](int a, int g) __attribute__((always_inline)) {   // -> float index of (pixel, image ib*64) inside a channel plane
+      const int ys = sy_l + dir * a;
+      const int sx = g ? sx1_l : sx_l;
+      const bool xin = g ? xin1_l : xin0_l, valid = g ? valid1_l : valid0_l;
+      const unsigned off = (unsigned)((ys * SW + sx) * N + sib_l);
+      const bool in = xin && (unsigned)ys < (unsigned)SH;
+      const unsigned o1 = in ? off : kZeroSlot;
+      return valid ? o1 : kNoSlot;
+    };
+    const ptrdiff_t d4 = (ptrdiff_t)(4 * ch_bytes) - 1024;   // four channel planes on, minus the 1 KB the immediate offset adds
+    struct SlotIssue {
+      unsigned so, voff, ld, real;   // real: 0 / 1
+      const char *p0, *p1, *p2, *p3;
+    } si;
+    auto slot_kind = [&](int sl, unsigned ldbuf, unsigned soff, int enable) __attribute__((always_inline)) {
+      const unsigned neg = (unsigned)sl >> 31;
+      const int slc = sl & ~(-(int)neg);                                     // max(sl, 0)
+      si.so = (unsigned)__builtin_amdgcn_readlane((int)soff, slc);
+      const unsigned is_no = 1u - min(si.so + 1u, 1u), is_zero = 1u - min(si.so + 2u, 1u);   // so == kNoSlot, so == kZeroSlot
+      const unsigned none = (1u - (unsigned)enable) | neg | is_no;
+      si.real = (1u - none) & (1u - is_zero);
+      const unsigned ldr = ldbuf + (unsigned)slc * 4096u;
+      si.ld = ldr ^ ((ldr ^ lds_dump) & (0u - none));                        // none ? dump : slot
+      si.voff = lane_off_raw & (0u - si.real);
+    };
+    auto slot_addr = [&](const char* src) __attribute__((always_inline)) {
+      const ptrdiff_t m = -(ptrdiff_t)si.real;
+      const char* const rbase = src + (size_t)si.so * 4;   // wave-uniform: k-row 0 of the slot
+      const char* const base = zero_page + ((rbase - zero_page) & m);
+      const ptrdiff_t st = (ptrdiff_t)-1024 + ((d4 + 1024) & m);
+      si.p0 = uniform_ptr(base);
+      si.p1 = uniform_ptr(base + st);
+      si.p2 = uniform_ptr(base + 2 * st);
+      si.p3 = uniform_ptr(base + 3 * st);
+    };
+    auto slot_go = [&]() __attribute__((always_inline)) {   // (prologue)
+      lds_dma4_rfl(si.voff, si.p0, si.p1, si.p2, si.p3, (unsigned)__builtin_amdgcn_readfirstlane((int)si.ld));
+    };
+    auto slot_piece = [&](auto J) __attribute__((always_inline)) {
+      constexpr int j = decltype(J)::value;
+      lds_dma_piece_rfl<j>(si.voff, j == 0 ? si.p0 : j == 1 ? si.p1 : j == 2 ? si.p2 : si.p3, (unsigned)__builtin_amdgcn_readfirstlane((int)si.ld));
+    };
+    auto slot_piece_if = [&](int on, auto J) __attribute__((always_inline)) {
+      constexpr int j = decltype(J)::value;
+      lds_dma_piece_if_rfl<j>(on, si.voff, j == 0 ? si.p0 : j == 1 ? si.p1 : j == 2 ? si.p2 : si.p3, (unsigned)__builtin_amdgcn_readfirstlane((int)si.ld));
+    };
+
+    // ================================ consumer state ================================
+    const int boff = S_l * 1024 + lh * 64 + NTC * (li & 15);   // floats inside a slab: slot base + k-row lh + first image
+    auto load_a = [&](int st, Split8 (&fa)[MT]) __attribute__((always_inline)) {
+      const u32x4* ap = reinterpret_cast<const u32x4*>(As + st * A_STAGE) + lh * ROWS + li;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        fa[t].h = ap[t * 32];
+        fa[t].m = ap[2 * ROWS + t * 32];
+        fa[t].l = ap[4 * ROWS + t * 32];
+      }
+    };
+    int stage = 0, ti = 0, sc = sc_beg, g_cur = g_beg, cnt_cur = g_beg ? cnt1 : cnt0;
+    unsigned bufsel = 0;   // 0 / 1: the slab buffer the MFMAs read
+    f32x4 bv[8];
+    auto read_b = [&]() __attribute__((always_inline)) {
+      const float* bs = Bs + bufsel * SLAB + ti * 1024 + boff;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[j] = ld4(bs + 2 * j * 64);
+    };
+    // the wave's three slots of a slab rotate with its slot loads: one per chunk of a 3-chunk superchunk, two and one in a 2-chunk one
+    int o0 = my_ord[0], o1 = my_ord[1], o2 = my_ord[2];
+    auto next_slot_kind = [&](int on) __attribute__((always_inline)) {   // on = 0: no slot this time — a dump load's description, no rotation
+      slot_kind(o0, lds_b + (bufsel ^ 1u) * (SLAB * 4u), slot_desc(a_lo + B_r, B_g), on & (int)((unsigned)(sc + 1 - sc_end) >> 31));   // sc + 1 < sc_end
+      const int m = -on, r0 = o0 ^ o1, r1 = o1 ^ o2, r2 = o2 ^ o0;
+      o0 ^= r0 & m;   // on: (o0, o1, o2) <- (o1, o2, o0)
+      o1 ^= r1 & m;
+      o2 ^= r2 & m;
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+      const int t1 = ti + 1, w = 1 - (int)((unsigned)(t1 - cnt_cur) >> 31);   // w = 1 when the superchunk is complete
+      ti = t1 & (w - 1);
+      bufsel ^= (unsigned)w;
+      sc += w;
+      const int g1 = g_cur + w, wg = 1 - (int)((unsigned)(g1 - ng) >> 31);
+      g_cur = g1 - (ng & -wg);
+      cnt_cur = cnt0 + ((cnt1 - cnt0) & -g_cur);
+      slab_next(w);
+      const int s1 = stage + 1, ws = 1 - (int)((unsigned)(s1 - STA) >> 31);   // ws = 1: wrap
+      stage = s1 - (STA & -ws);
+    };
+
+    // prologue: slab 0, filter chunks 0 and 1
+    {
+      const unsigned so = slot_desc(a_lo + B_r, B_g);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        slot_kind(my_ord[q], lds_b, so, 1);
+        slot_addr(slab_src);
+        slot_go();
+      }
+      slab_next(1);
+    }
+    issue_a();
+    issue_a();   // (two ahead)
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+    __syncthreads();
+
+    Split8 fa0[MT], fa1[MT], fb[2];
+    static_assert(NTC % 2 == 0, "column parity of fb is carried across chunks");
+    // gpw_kernel's fenced steps: one of the six products of split_mac, in its order, over the MT row tiles
+    auto mac_step = [&](auto K, const Split8 (&fa)[MT], const Split8& b, int u) __attribute__((always_inline)) {
+      constexpr int k = decltype(K)::value;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const u32x4& av = k == 0 || k == 4 ? fa[t].m : k == 2 ? fa[t].l : fa[t].h;   // (m,m) (h,l) (l,h) (h,m) (m,h) (h,h)
+        const u32x4& bw = k == 0 || k == 3 ? b.m : k == 1 ? b.l : b.h;
+        acc[t][u] = mma_bf16(av, bw, acc[t][u]);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto split_pair = [&](int u, int q, Split8& f) __attribute__((always_inline)) {
+      const float x0 = bv[2 * q][u], x1 = bv[2 * q + 1][u];
+      const unsigned H = pk_bf16(x0, x1);
+      const float r0 = x0 - __uint_as_float(H << 16), r1 = x1 - __uint_as_float(H & 0xffff0000u);
+      const unsigned M = pk_bf16(r0, r1);
+      const float s0 = r0 - __uint_as_float(M << 16), s1 = r1 - __uint_as_float(M & 0xffff0000u);
+      f.h[q] = H;
+      f.m[q] = M;
+      f.l[q] = pk_bf16(s0, s1);
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    using K3 = std::integral_constant<int, 3>;
+    using K4 = std::integral_constant<int, 4>;
+    using K5 = std::integral_constant<int, 5>;
+    // one chunk = one tap of the slab.  Column 0: the filter chunk's three pieces, the first slot's kind and addresses; column 1: that
+    // slot's four pieces, the filter iterator, the SECOND slot's kind and addresses; column 2: the second slot's pieces, the counters
+    // of the next chunk; the chunk barrier; column 3 with the next chunk's LDS reads and the split of its column 0.
+    // The second slot exists only in the first chunk of a two-chunk superchunk (`two`, scalar).  Two chunk bodies chosen by a branch
+    // would be the obvious form — and the register allocator then fails to give the 256 accumulators the same registers on both
+    // paths (it spilled accumulator tuples at every merge: 1.1 KB of scratch) — so there is ONE body; the second slot's description is
+    // always computed (disabled: a dump slot, no rotation of the wave's slots) and only its four load instructions and the count of
+    // the closing wait depend on `two` — with the scalar branch INSIDE the asm statement (lds_dma_piece_if_rfl, wait_vm_7_or_11):
+    // as C++ `if`s the same five branches made the compiler keep every loop iterator in vector registers (+100 VALU per chunk).
+    auto chunk = [&](Split8 (&fa)[MT], Split8 (&fan)[MT]) __attribute__((always_inline)) {
+      const int two = sgpr((int)(1u - min((unsigned)(((cnt_cur - 2) | ti)), 1u)));   // cnt_cur == 2 && ti == 0
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u + 1 < NTC; ++u) {
+        Split8& fn = fb[(u + 1) & 1];
+        const Split8& fc = fb[u & 1];
+        if (u == 2) slot_piece_if(two, K0{});
+        split_pair(u + 1, 0, fn);
+        if (u == 0) issue_a_addr();
+        if (u == 1) slot_piece(K0{});
+        mac_step(K0{}, fa, fc, u);
+        if (u == 2) slot_piece_if(two, K1{});
+        split_pair(u + 1, 1, fn);
+        if (u == 0) issue_a_piece(K0{});
+        if (u == 1) slot_piece(K1{});
+        mac_step(K1{}, fa, fc, u);
+        if (u == 2) slot_piece_if(two, K2{});
+        split_pair(u + 1, 2, fn);
+        if (u == 0) issue_a_piece(K1{});
+        if (u == 1) slot_piece(K2{});
+        mac_step(K2{}, fa, fc, u);
+        if (u == 2) slot_piece_if(two, K3{});
+        split_pair(u + 1, 3, fn);
+        if (u == 0) issue_a_piece(K2{});
+        if (u == 1) slot_piece(K3{});
+        mac_step(K3{}, fa, fc, u);
+        if (u == 0) next_slot_kind(1);
+        if (u == 1) issue_a_step();
+        if (u == NTC - 2) advance();
+        mac_step(K4{}, fa, fc, u);
+        if (u == 0) slot_addr(slab_src);
+        if (u == 1) {
+          next_slot_kind(two);
+          slot_addr(slab_src);
+        }
+        mac_step(K5{}, fa, fc, u);
+      }
+      CHIP_PIN_SPLIT8(fb[(NTC - 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      // everything this wave issued before this chunk's batch (7 loads, or 11) has landed: vmcnt(7 | 11) lgkmcnt(0)
+      wait_vm_7_or_11(two);
+      __syncthreads();                      // ... and every other wave's; every wave has read this chunk's A and slab slots out of LDS
+      {
+        const Split8& fc = fb[(NTC - 1) & 1];
+        Split8& fn = fb[NTC & 1];
+        read_b();
+        mac_step(K0{}, fa, fc, NTC - 1);
+        load_a(stage, fan);
+        mac_step(K1{}, fa, fc, NTC - 1);
+        split_pair(0, 0, fn);
+        mac_step(K2{}, fa, fc, NTC - 1);
+        split_pair(0, 1, fn);
+        mac_step(K3{}, fa, fc, NTC - 1);
+        split_pair(0, 2, fn);
+        mac_step(K4{}, fa, fc, NTC - 1);
+        split_pair(0, 3, fn);
+        mac_step(K5{}, fa, fc, NTC - 1);
+        CHIP_PIN_SPLIT8(fn);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    auto run = [&](Split8 (&fa)[MT], Split8 (&fan)[MT]) __attribute__((always_inline)) { chunk(fa, fan); };
+    load_a(0, fa0);
+    read_b();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split_pair(0, q, fb[0]);
+    int c = 0;
+    if (nchunks & 1) {
+      run(fa0, fa1);
+      c = 1;
+    } else {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) fa1[t] = fa0[t];
+    }
+    for (; c < nchunks; c += 2) {
+      run(fa1, fa0);
+      run(fa0, fa1);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);   // the last two batches (dump / free-stage loads) before the LDS is released
+  }
+
+  // ---- epilogue: gg_kernel's, with the unit column mapping (GGParams::patch); every accumulator read straight out of its AGPR
+  acc_settle();
+  if (tsplit >= 0) {
+    float* pp = p.tail_partial + ((size_t)(L - p.tail_first) * p.tail_splits + tsplit) * (size_t)(ROWS * WC * CW);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        fvec v;
+#pragma unroll
+        for (int u = 0; u < NTC; ++u) v[u] = acc_elem<true>(acc[t][u][reg]);
+        *reinterpret_cast<fvec*>(pp + ((size_t)(t * 16 + reg) * NC + tid) * NTC) = v;
+      }
+    return;
+  }
+  gg_epilogue<1, WC, MT, CW, true, true>(p, acc, row_tile, col_tile, split, T.ncols, T.GX, T.G, T.dy0, T.dx0);
 }
 
 namespace {
@@ -1139,8 +1608,8 @@ int patch_slots(Kern kern, int threads, size_t lds) {
   return (n < 1 ? 1 : n) * 256;
 }
 
-// gpw_kernel's split-K by wave quantisation (gg_launch_cfg's rule; the unit of a K-range is the superchunk) and its LAUNCH POLICY.
-// A 128 x 512 tile with 512-register waves owns its CU, so a launch is rounds of `slots` blocks and nothing fills a partial one.
+// gpw_kernel's / gpv_kernel's split-K by wave quantisation (gg_launch_cfg's rule; the unit of a K-range is the superchunk) and their
+// LAUNCH POLICY.  A 128 x 512 tile with 512-register waves owns its CU, so a launch is rounds of `slots` blocks and nothing fills a partial one.
 // Measured on the MI355X (profiles/r05_wide_kernels.md): one round that fills the chip beats ggp_kernel by 7-12 % (conv3 fprop, conv4,
 // conv5 with and without two K-ranges), a K-split over TWO rounds loses to ggp_kernel's tail split (conv3 dgrad: 170 tiles, 3 ranges,
 // 435 + 37 us against 343 + 23) — every extra round pays the 256 KB write-out and the prologue again.  So: take the launch when the
@@ -1149,12 +1618,16 @@ struct WidePlan {
   int splits;
   bool take;
 };
+// row tile of the wide kernels: 96 rows (gpv_kernel<3>) for 65..96-row problems — conv2's input gradient — else 128
+inline int wide_rows(int R) { return R > 64 && R <= 96 ? 96 : 128; }
+// which of them runs a single-problem launch: gpw_kernel keeps what it was validated on (one group of three taps, 128-row tiles)
+inline bool wide_is_var(const GGParams& p) { return !(p.ng == 1 && p.gcnt[0] == 3 && wide_rows(p.R) == 128); }
 inline WidePlan wide_plan(const GGParams& p, size_t dst_elems, int slots) {
-  const int CB = p.KC / BK, TYn = p.TYX / p.TX;
-  const int tiles = divup(p.R, 128) * divup((p.N / 64) * p.G, kWideP);
-  const int nsc = CB * TYn, kchunks = CB * p.TYX;
+  const int CB = p.KC / BK, TYn = p.TYX / p.TX, rows = wide_rows(p.R);
+  const int tiles = divup(p.R, rows) * divup((p.N / 64) * p.G, kWideP);
+  const int nsc = CB * TYn * p.ng, kchunks = CB * p.TYX;
   const double block_rate = 230e12 / slots;
-  const double fl = 2.0 * 128 * (double)(kWideP * 64) * (double)p.K;
+  const double fl = 2.0 * rows * (double)(kWideP * 64) * (double)p.K;
   int splits = 1;
   if (dst_elems > 0 && kchunks >= 16) {
     double best_t = 1e30;
@@ -1175,17 +1648,20 @@ inline WidePlan wide_plan(const GGParams& p, size_t dst_elems, int slots) {
   const bool fill = (double)blocks >= 0.85 * (double)(rounds * slots) || (splits == 1 && rounds >= 4);   // (many rounds: the tail split evens the last)
   return {splits, fill && (splits == 1 || rounds == 1)};
 }
-constexpr size_t kWideLds = sizeof(float) * (3 * (6 * 128 * 4) + 2 * (kWideNS * 1024) + 1024);   // filter ring + two slabs + the dump slot
-inline int wide_slots() {
+constexpr size_t wide_lds(int rows) { return sizeof(float) * (3 * (6 * rows * 4) + 2 * (kWideNS * 1024) + 1024); }   // filter ring + two slabs + the dump slot
+constexpr size_t kWideLds = wide_lds(128);
+inline int wide_slots(int rows = 128, bool var = false) {
   static const int n = patch_slots(gpw_kernel, 256, kWideLds);
-  return n;
+  if (!var) return n;
+  static const int n4 = patch_slots(gpv_kernel<4>, 256, wide_lds(128)), n3 = patch_slots(gpv_kernel<3>, 256, wide_lds(96));
+  return rows == 96 ? n3 : n4;
 }
 
 }  // namespace
 
 // Can this gather (GGParams filled by conv_up_impl / conv_down_impl for ggp_kernel's tap-major pre-split path: KC > 0, apre) run on
-// gpp_kernel / gpw_kernel?  Fills the tap groups.  A tap row is cut into ssx groups of taps that are ssx apart (one group for a
-// stride-1 gather): inside a group neighbouring pixels' taps coincide, slot i of pixel j+1 = slot i+1 of pixel j.
+// gpp_kernel / gpw_kernel / gpv_kernel?  Fills the tap groups.  A tap row is cut into ssx groups of taps that are ssx apart (one group for
+// a stride-1 gather): inside a group neighbouring pixels' taps coincide, slot i of pixel j+1 = slot i+1 of pixel j.
 // dst_elems: the size of the whole destination when the launch may be cut in K (0: it may not).
 bool patch_shape_ok(GGParams& p, size_t dst_elems) {
   if (!patch_mode() || matrix_path() == 0 || p.KC <= 0 || p.KC % BK != 0) return false;
@@ -1200,10 +1676,11 @@ bool patch_shape_ok(GGParams& p, size_t dst_elems) {
     p.gb0[r] = p.dir > 0 ? r : r + (cnt - 1) * p.ssx;
   }
   if (p.ng == 1) { p.gcnt[1] = p.gcnt[0]; p.gb0[1] = p.gb0[0]; }
-  // gpw_kernel: 3-tap rows of a stride-1 gather; its 12 slots hold ONE wrap per tile: output rows of >= 8 pixels
+  // the wide kernels: their 12 slots hold ONE wrap per tile: output rows of >= 8 pixels.  gpw_kernel: one group of three taps (the
+  // 3 x 3 stride-1 layers); gpv_kernel: any groups of three and two (5 x 5 stride 2: {0,2,4} / {1,3}), 96-row tiles
   if (patch_mode() >= 3) {
-    if (p.ng != 1 || p.gcnt[0] != 3 || p.GX < kWideP) return false;
-    return patch_mode() == 4 || wide_plan(p, dst_elems, wide_slots()).take;   // (mode 4: the parity tests' small shapes, A/B runs)
+    if (p.GX < kWideP) return false;
+    return patch_mode() == 4 || wide_plan(p, dst_elems, wide_slots(wide_rows(p.R), wide_is_var(p))).take;   // (mode 4: the parity tests' small shapes, A/B runs)
   }
   return true;
 }
@@ -1212,12 +1689,14 @@ bool patch_shape_ok(GGParams& p, size_t dst_elems) {
 // then the gather-GEMM on them.  `op` / `flops` feed the kernel timers (algorithmic work of the call).
 void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, const PatchBank& bank) {
   constexpr int WR = 2, WC = 2, MT = 2, CW = 128;   // gpp_kernel
-  constexpr int ROWS = 128;                         // both kernels
-  static_assert(ROWS == WR * MT * 32, "row tile");
+  static_assert(128 == WR * MT * 32, "row tile");
   // CONVNET_GG_PATCH / convnet_hip_set_patch_mode: 1 = gpp_kernel on a raw fp32 slab, split by the consumers; 2 = gpp_kernel on bf16
-  // planes of the source tensor (one more pass); 3 = gpw_kernel (8 units x 128 rows, raw slab, no producer wave) where wide_plan takes the launch, 4 = wherever the shape allows
+  // planes of the source tensor (one more pass); 3 = the wide kernels (8 units x 128 / 96 rows, raw slab, no producer wave: gpw_kernel,
+  // gpv_kernel) where wide_plan takes the launch, 4 = wherever the shape allows
   const int mode = patch_mode();
   const bool wide = mode >= 3, braw = mode != 2;
+  const bool var = wide && wide_is_var(p);
+  const int ROWS = wide ? wide_rows(p.R) : 128;
   const int PU = wide ? kWideP : kPatchP;           // units per tile
   const int TCOLS = PU * 64;                        // columns per tile
   const int threads = wide ? 256 : WR * WC * 64 + 64;
@@ -1225,7 +1704,7 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
   const size_t elems = (size_t)C * HW * N;
   const int RT = divup(p.R, ROWS);
   {
-    // filter bank -> [chunk][row tile][plane, k-group][128 rows] bf16 planes
+    // filter bank -> [chunk][row tile][plane, k-group][ROWS rows] bf16 planes
     const size_t welems = (size_t)CB * p.TYX * RT * ROWS * 16;
     u32x4* ap = static_cast<u32x4*>(workspace_aux(welems * 6));
     filter_planes_rt_launch(bank, ap, p.TYX, ROWS, op);
@@ -1250,11 +1729,11 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
   p.col_tiles = divup(p.IB * p.G, PU);
   p.zero = zero_page();
   p.prio = CHIP_DIAG_KNOB("CONVNET_GPP_DIAG", 0);
-  constexpr size_t lds_p = sizeof(float) * (3 * (6 * ROWS * 4) + 2 * (6 * 8 * 256)), lds_r = sizeof(float) * (3 * (6 * ROWS * 4) + 2 * (4 * 8 * 256));
-  constexpr size_t lds_w = kWideLds;
+  constexpr size_t lds_p = sizeof(float) * (3 * (6 * 128 * 4) + 2 * (6 * 8 * 256)), lds_r = sizeof(float) * (3 * (6 * 128 * 4) + 2 * (4 * 8 * 256));
+  const size_t lds_w = wide_lds(ROWS);
   static const int slots_p = patch_slots(gpp_kernel<WR, WC, MT, CW, false>, WR * WC * 64 + 64, lds_p);
   static const int slots_r = patch_slots(gpp_kernel<WR, WC, MT, CW, true>, WR * WC * 64 + 64, lds_r);
-  const int slots = wide ? wide_slots() : braw ? slots_r : slots_p;
+  const int slots = wide ? wide_slots(ROWS, var) : braw ? slots_r : slots_p;
   const int tiles = p.row_tiles * p.col_tiles;
   const int TYn = p.TYX / p.TX;
   const int nsc = CB * TYn * p.ng;                    // superchunks of a whole reduction
@@ -1313,18 +1792,67 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
   static const GGClassTable kNone = {};
   {
     // (",split" in a timer name is how bench.py prices the kernel on the bf16 pipe: kernel_peak)
-    KernelTimer timer(wide ? "gpw_kernel<128x512,split,raw>" : braw ? "gpp_kernel<2,2,2,128,split,raw>" : "gpp_kernel<2,2,2,128,split,planes>", op, flops, 0.0, 0.0);
-    if (wide) hipLaunchKernelGGL(gpw_kernel, grid, dim3(threads), lds_w, stream(), p, kNone);
+    KernelTimer timer(var ? (ROWS == 96 ? "gpv_kernel<96x512,split,raw>" : "gpv_kernel<128x512,split,raw>")
+                      : wide ? "gpw_kernel<128x512,split,raw>" : braw ? "gpp_kernel<2,2,2,128,split,raw>" : "gpp_kernel<2,2,2,128,split,planes>", op, flops, 0.0, 0.0);
+    if (var && ROWS == 96) hipLaunchKernelGGL(gpv_kernel<3>, grid, dim3(threads), lds_w, stream(), p, kNone);
+    else if (var) hipLaunchKernelGGL(gpv_kernel<4>, grid, dim3(threads), lds_w, stream(), p, kNone);
+    else if (wide) hipLaunchKernelGGL(gpw_kernel, grid, dim3(threads), lds_w, stream(), p, kNone);
     else if (braw) hipLaunchKernelGGL((gpp_kernel<WR, WC, MT, CW, true>), grid, dim3(threads), lds_r, stream(), p, kNone);
     else hipLaunchKernelGGL((gpp_kernel<WR, WC, MT, CW, false>), grid, dim3(threads), lds_p, stream(), p, kNone);
   }
   if (p.tail_splits > 1) {
     const int rem = tiles - p.tail_first;
     KernelTimer timer("gg_tail_fix_kernel", op, 0.0, sizeof(float) * (double)rem * (p.tail_splits + 1) * ROWS * TCOLS);
-    if (wide) hipLaunchKernelGGL(gpw_tail_fix_kernel, dim3(rem * kTailFixParts), dim3(256), 0, stream(), p);
+    if (wide && ROWS == 96) hipLaunchKernelGGL(gpw_tail_fix_kernel<3>, dim3(rem * kTailFixParts), dim3(256), 0, stream(), p);
+    else if (wide) hipLaunchKernelGGL(gpw_tail_fix_kernel<4>, dim3(rem * kTailFixParts), dim3(256), 0, stream(), p);
     else hipLaunchKernelGGL((gg_tail_fix_kernel<WR, WC, MT, CW, true>), dim3(rem * kTailFixParts), dim3(WR * WC * 64), 0, stream(), p);
   }
   if (splits > 1) gg_reduce_launch(p, dst_elems, splits, op);
+}
+
+// All stride classes of a strided input gradient in ONE gpv_kernel launch (conv2: 5 x 5 stride 2 -> classes of 3x3, 3x2, 2x3, 2x2
+// taps, each a stride-1 gather over the derivative map; ggp_kernel's gg_launch_classes is the fallback).  `base` as conv_down_impl
+// fills it for the tap-major pre-split path (KC = filters, apre, dir = -1, ssx = 1); the classes carry their banks as bf16 planes per
+// row tile of wide_rows(R) rows (gg_tile_rows gives the same height).  Fills ncols / col_tiles / tile_end.  False: not this shape.
+bool patch_classes_ok(const GGParams& base, const GGClassTable& ct) {
+  if (patch_mode() < 3 || matrix_path() == 0 || !base.apre || base.KC <= 0 || base.KC % BK != 0) return false;
+  if (base.N % 64 != 0 || base.R <= 64 || base.dir >= 0 || base.ssx != 1 || base.ssy != 1) return false;
+  if ((size_t)base.SH * base.SW * base.N >= (size_t(1) << 28)) return false;
+  if (ct.n < 1) return false;
+  for (int i = 0; i < ct.n; ++i)
+    if (ct.c[i].TX < 2 || ct.c[i].TX > 3 || ct.c[i].GX < kWideP || ct.c[i].TYX % ct.c[i].TX != 0) return false;
+  return true;
+}
+void patch_run_classes(GGParams& p, GGClassTable& ct, const char* op, double flops, double exec) {
+  const int ROWS = wide_rows(p.R);
+  p.patch = 1;
+  p.IB = p.N / 64;
+  p.planes = nullptr;
+  p.NP = p.N;
+  p.ncols = 0;
+  p.row_tiles = divup(p.R, ROWS);
+  p.zero = zero_page();
+  p.prio = 0;
+  p.splits = 1;
+  p.chunks_per_split = 1 << 24;
+  p.partial = nullptr;
+  p.slab = 0;
+  p.tail_splits = 1;
+  p.tail_partial = nullptr;
+  p.ng = 1;
+  std::sort(ct.c, ct.c + ct.n, [](const GGClass& a, const GGClass& b) { return a.K > b.K; });
+  int end = 0;
+  for (int i = 0; i < ct.n; ++i) {
+    ct.c[i].ncols = 0;
+    ct.c[i].col_tiles = divup(p.IB * ct.c[i].G, kWideP);
+    end += p.row_tiles * ct.c[i].col_tiles;
+    ct.c[i].tile_end = end;
+  }
+  p.col_tiles = ct.c[0].col_tiles;
+  wide_slots(ROWS, true);   // (the kernel's LDS opt-in)
+  KernelTimer timer(ROWS == 96 ? "gpv_kernel<96x512,split,raw>" : "gpv_kernel<128x512,split,raw>", op, flops, 0.0, exec);
+  if (ROWS == 96) hipLaunchKernelGGL(gpv_kernel<3>, dim3(end), dim3(256), wide_lds(96), stream(), p, ct);
+  else hipLaunchKernelGGL(gpv_kernel<4>, dim3(end), dim3(256), wide_lds(128), stream(), p, ct);
 }
 
 }  // namespace chip

@@ -221,8 +221,8 @@ static std::string gname(const Geo& g) {
   return "N" + std::to_string(g.N) + " C" + std::to_string(g.C) + " " + std::to_string(g.H) + "x" + std::to_string(g.W) + " F" + std::to_string(g.F) + " k" +
          std::to_string(g.Ky) + " s" + std::to_string(g.sy) + " p" + std::to_string(g.pad);
 }
-static void abi_conv_case(const Geo& g, const char* which) {
-  convnet_hip_set_patch_mode(0);
+static void abi_conv_case(const Geo& g, const char* which, int patch_mode = 0) {
+  convnet_hip_set_patch_mode(patch_mode);
   convnet_hip_set_wgrad_tile(0);
   const int My = g.My(), Mx = g.Mx(), TYX = g.Ky * g.Kx, K = g.C * TYX;
   auto xv = rnd((size_t)g.C * g.H * g.W * g.N, 11), wv = rnd((size_t)g.F * K, 12), yv = rnd((size_t)g.F * My * Mx * g.N, 13), bv = rnd(g.F, 14);
@@ -267,7 +267,7 @@ static void abi_conv_case(const Geo& g, const char* which) {
             ref[((size_t)(c * g.H + iy) * g.W + ix) * g.N + n] = s;
           }
     convDown(&my, &mw, &mx, &sy, &sw, &sx, desc(g), 0.f);
-    verdict("abi convDown " + gname(g), rel_err(x, ref), true);
+    verdict("abi convDown " + gname(g) + " [" + chip::g_last_kernel + "]", rel_err(x, ref), patch_mode == 0 || std::string(chip::g_last_kernel).find("gpw") == 0);
   } else {   // "outp": weight gradients + bias gradient
     std::vector<double> ref((size_t)g.F * K), refb(g.F);
     for (int f = 0; f < g.F; ++f) {
@@ -397,7 +397,7 @@ static void sgd_case(int rows, int cols) {
 }
 
 int main(int argc, char** argv) {
-  const std::string what = argc > 1 ? argv[1] : "quick";   // abi | gpp | gpw | gpwvar | gpwtail | wgw | wgwvar | wgwfin | quick (a subset of each, ~1 minute) | all
+  const std::string what = argc > 1 ? argv[1] : "quick";   // abi | gpp | gpw | gpv | gpvtail | gpwtail | wgw | wgwvar | wgwfin | quick (a subset of each, ~1 minute) | all
   const bool all = what == "all", quick = what == "quick";   // ("all" does not include gpwtail: its 8-slot chip is a process-wide setting)
   if (what == "abi" || all || quick) {   // the default kernels through the C ABI: the calibration of the harness (green on hardware)
     abi_conv_case(Geo{64, 16, 9, 9, 128, 3, 3, 1, 1, 1}, "up");      // ggp_kernel<2,2,2,128>, pre-split filter planes
@@ -428,6 +428,25 @@ int main(int argc, char** argv) {
     if (!quick) fprop_case(Geo{64, 16, 10, 10, 72, 3, 3, 1, 1, 0}, 4, "gpw");   // pad 0: 8-wide output rows
     dgrad_case(Geo{64, 96, 9, 9, 16, 3, 3, 1, 1, 1}, 4, "gpw");
     if (!quick) dgrad_case(Geo{64, 72, 10, 10, 32, 3, 3, 1, 1, 0}, 4, "gpw");   // conv5 type: 8 x 8 derivatives into 10 x 10
+  }
+  if (what == "gpv" || all || quick) {   // gpv_kernel: tap rows in groups of three and two (patch_gemm.hip)
+    fprop_case(Geo{64, 16, 23, 23, 96, 5, 5, 2, 2, 0}, 4, "gpv");      // conv2's form ({0,2,4} / {1,3}) on the 96-row build: 10-wide output rows, ragged last tile
+    abi_conv_case(Geo{64, 96, 19, 19, 16, 5, 5, 2, 2, 0}, "down", 3);  // conv2's input gradient: classes of 3x3, 3x2, 2x3, 2x2 taps in one launch, 96 rows
+    if (!quick) {
+      fprop_case(Geo{64, 16, 21, 21, 130, 5, 5, 2, 2, 0}, 4, "gpv");   // 128-row build, partial second row tile, 9-wide rows: a wrap in almost every tile
+      fprop_case(Geo{128, 32, 19, 19, 96, 5, 5, 2, 2, 0}, 4, "gpv");   // two image blocks, two channel blocks
+      fprop_case(Geo{64, 16, 21, 25, 96, 5, 5, 2, 2, 2}, 4, "gpv");    // padding 2: border columns on the zero page, whole tap rows skipped, rectangular
+      fprop_case(Geo{64, 16, 20, 20, 128, 4, 4, 2, 2, 1}, 4, "gpv");   // 4 x 4 stride 2: groups of two and two
+      fprop_case(Geo{64, 16, 10, 10, 128, 2, 2, 1, 1, 0}, 4, "gpv");   // one group of two: every superchunk is (two slots, one slot)
+      fprop_case(Geo{64, 16, 9, 9, 72, 3, 3, 1, 1, 1}, 4, "gpv");      // gpw_kernel's 3 x 3 stride-1 case on the 96-row build
+      abi_conv_case(Geo{64, 132, 17, 21, 16, 5, 5, 2, 2, 2}, "down", 3);   // 128-row build, two row tiles, padded: classes start at different pixels
+      abi_conv_case(Geo{64, 96, 20, 20, 16, 4, 4, 2, 2, 1}, "down", 3);    // four classes of 2 x 2 taps
+    }
+  }
+  if (what == "gpvtail") {   // 13 tiles on an 8-slot "chip", the last round's 5 tiles cut in 3 K-ranges (ranges begin inside a tap row's groups)
+    setenv("CONVNET_EMU_SLOTS", "8", 1);
+    setenv("CONVNET_EMU_TAIL", "3", 1);
+    fprop_case(Geo{64, 32, 23, 23, 96, 5, 5, 2, 2, 0}, 4, "gpv(tail split)");
   }
   if (what == "gpwtail") {   // 11 tiles on an 8-slot "chip", the last round's 3 tiles cut in 3 K-ranges: tail split + gpw_tail_fix_kernel
     setenv("CONVNET_EMU_SLOTS", "8", 1);   // (read once, at the first patch_run of the mode: run this leg in its own process)

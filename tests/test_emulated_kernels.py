@@ -60,6 +60,8 @@ def test_wide_kernels_run_correctly_in_emulation(emu_binary):
     assert any(l.startswith("PASS abi convUp") for l in lines) and any(l.startswith("PASS abi convOutpBias") for l in lines)
     assert any(l.startswith("PASS gpp(raw)") for l in lines) and any(l.startswith("PASS gpw fprop") for l in lines)
     assert any(l.startswith("PASS gpw dgrad") for l in lines) and any(l.startswith("PASS wgw wgrad") for l in lines)
+    # gpv_kernel: conv2's forward form and its four stride classes (the latter through convDown)
+    assert any(l.startswith("PASS gpv fprop") for l in lines) and any(l.startswith("PASS abi convDown") and "k5 s2" in l and "gpw_kernel(dgrad)" in l for l in lines)
 
 
 def test_wide_wgrad_kernel_single_block_epilogue_in_emulation(emu_binary):
@@ -74,5 +76,13 @@ def test_wide_patch_kernel_tail_split_in_emulation(emu_binary):
     """11 tiles on an 8-slot "chip": the last round's three tiles are cut into three K-ranges (the kernel's tail-split branch, its raw
     partial tiles, gpw_tail_fix_kernel) — forced by the harness, the cost model never picks it at emulation sizes"""
     r = subprocess.run([emu_binary, "gpwtail"], capture_output=True, text=True, timeout=1200)
+    lines = r.stdout.strip().splitlines()
+    assert r.returncode == 0 and lines[-1] == "ALL PASSED" and "tail_splits=3" in lines[0], r.stdout + r.stderr
+
+
+def test_group_patch_kernel_tail_split_in_emulation(emu_binary):
+    """gpv_kernel (5 x 5 stride 2: superchunks of three and two chunks): 13 tiles on an 8-slot "chip", the last round's five tiles cut
+    into three K-ranges whose borders fall inside a tap row's groups"""
+    r = subprocess.run([emu_binary, "gpvtail"], capture_output=True, text=True, timeout=1200)
     lines = r.stdout.strip().splitlines()
     assert r.returncode == 0 and lines[-1] == "ALL PASSED" and "tail_splits=3" in lines[0], r.stdout + r.stderr

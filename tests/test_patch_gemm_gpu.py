@@ -247,3 +247,78 @@ def test_wide_tail_split_on_hardware(hip):
             assert any(n == "gg_tail_fix_kernel" for n in names), names
     _lib.lib.convnet_hip_set_patch_mode(DEFAULT_MODE)
     assert rel_err(outs[1], outs[0]) < 1e-5
+
+
+# ---- gpv_kernel (round 6; patch modes 3 / 4): gpw_kernel's tile for tap rows cut into groups of three and two taps — 5 x 5 stride 2
+# forward ({0,2,4} / {1,3}: AlexNet's conv2), the stride classes of its input gradient (3- and 2-tap rows, all classes in one launch),
+# and a 96-row build for 65..96-row problems.  Mechanisms: superchunks of three and two chunks, two slots per wave in the first chunk of
+# a two-chunk superchunk, K-ranges that begin inside a tap row's groups, the quarter piece of the 96-row filter chunk.  Against the
+# CPU oracle; every case asserts from the kernel timers that gpv_kernel is what ran.
+VAR_FPROP = [
+    Geom(N=64, C=32, H=23, W=23, F=96, Ky=5, Kx=5, sy=2, sx=2),                  # conv2's form on the 96-row build, 10-wide rows, split-K
+    Geom(N=128, C=80, H=21, W=21, F=144, Ky=5, Kx=5, sy=2, sx=2),                # 128-row build, partial row tile, 9-wide rows (wraps), two image blocks
+    Geom(N=64, C=16, H=21, W=25, F=96, Ky=5, Kx=5, sy=2, sx=2, pady=2, padx=2),  # padded: border columns from the zero page, tap rows skipped
+    Geom(N=64, C=16, H=20, W=20, F=128, Ky=4, Kx=4, sy=2, sx=2, pady=1, padx=1), # groups of two and two
+    Geom(N=64, C=32, H=10, W=10, F=128, Ky=2, Kx=2),                             # one group of two
+    Geom(N=64, C=32, H=9, W=9, F=72, Ky=3, Kx=3, pady=1, padx=1),                # 3 x 3 stride 1 on the 96-row build
+    Geom(N=192, C=16, H=19, W=19, F=80, Ky=5, Kx=5, sy=2, sx=2),                 # 8-wide rows, three image blocks
+    Geom(N=256, C=96, H=55, W=55, F=256, Ky=5, Kx=5, sy=2, sx=2),                # conv2 itself: 676 tiles, tail split
+]
+VAR_DGRAD = [
+    Geom(N=64, C=96, H=19, W=19, F=32, Ky=5, Kx=5, sy=2, sx=2),                  # classes 3x3, 3x2, 2x3, 2x2 on the 96-row build
+    Geom(N=64, C=132, H=17, W=21, F=32, Ky=5, Kx=5, sy=2, sx=2, pady=2, padx=2), # 128-row build, two row tiles, classes start at different pixels
+    Geom(N=128, C=96, H=23, W=23, F=48, Ky=5, Kx=5, sy=2, sx=2),                 # two image blocks
+    Geom(N=64, C=96, H=20, W=20, F=16, Ky=4, Kx=4, sy=2, sx=2, pady=1, padx=1),  # four classes of 2 x 2 taps
+    Geom(N=256, C=96, H=55, W=55, F=256, Ky=5, Kx=5, sy=2, sx=2),                # conv2's input gradient itself
+]
+
+
+def _ran(hip_call):
+    """run hip_call with the kernel timers on; returns (result, names of the kernels that ran)"""
+    from convnet_amd import _lib
+    _lib.profile_enable(True)
+    out = hip_call()
+    names = [r["kernel"] for r in _lib.profile_report()]
+    _lib.profile_enable(False)
+    return out, names
+
+
+@pytest.mark.parametrize("g", VAR_FPROP, ids=_id)
+def test_group_tile_fprop_vs_oracle(hip, wide_mode, g):
+    rng = np.random.default_rng(41)
+    x, w = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape())
+    for st in ((0.0,) if g.N * g.C * g.F > 10 ** 6 else (0.0, 1.0)):
+        t0 = rnd(rng, g.out_shape())
+        got, names = _ran(lambda: hip.conv_up(g, x, w, t0.copy(), st))
+        assert any(n.startswith("gpv_kernel") for n in names), names
+        assert rel_err(got, oracle.port.conv_up(g, x, w, t0.copy(), st)) < TOL
+
+
+@pytest.mark.parametrize("g", VAR_DGRAD, ids=_id)
+def test_group_tile_dgrad_vs_oracle(hip, g):
+    """(default mode 3: the stride classes of a strided input gradient have no launch policy of their own)"""
+    rng = np.random.default_rng(42)
+    dy, w = rnd(rng, g.out_shape()), rnd(rng, g.filt_shape())
+    for st in ((0.0,) if g.N * g.C * g.F > 10 ** 6 else (0.0, 1.0)):
+        t0 = rnd(rng, g.in_shape())
+        got, names = _ran(lambda: hip.conv_down(g, dy, w, t0.copy(), st))
+        assert any(n.startswith("gpv_kernel") for n in names), names
+        assert rel_err(got, oracle.port.conv_down(g, dy, w, t0.copy(), st)) < TOL
+
+
+def test_group_tile_is_the_default_for_conv2(hip):
+    """mode 3 with its launch policy: AlexNet's conv2 at 256 images runs forward and backward on gpv_kernel (fprop: 676 tiles = two
+    whole rounds + a tail split), and the fused bias + ReLU epilogue equals the unfused sequence bit for bit"""
+    from convnet_amd import _lib
+    assert _lib.lib.convnet_hip_get_patch_mode() == DEFAULT_MODE
+    g = Geom(N=256, C=96, H=55, W=55, F=256, Ky=5, Kx=5, sy=2, sx=2)
+    rng = np.random.default_rng(43)
+    x, w, b = rnd(rng, g.in_shape()), rnd(rng, g.filt_shape()), rnd(rng, (g.F,))
+    y, names = _ran(lambda: hip.conv_up(g, x, w))
+    assert any(n.startswith("gpv_kernel<128x512") for n in names) and "gg_tail_fix_kernel" in names, names
+    fused = hip.conv_up_bias_relu(g, x, w, b, relu=True)
+    unfused = np.maximum(y + b.reshape(-1, 1, 1, 1), 0.0).astype(np.float32)
+    assert np.array_equal(fused, unfused)
+    dy = rnd(rng, g.out_shape())
+    _, names = _ran(lambda: hip.conv_down(g, dy, w))
+    assert any(n.startswith("gpv_kernel<96x512") for n in names), names
