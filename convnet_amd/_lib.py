@@ -111,6 +111,7 @@ def _load():
     sig("convnet_hip_last_kernel_info", None, P(KernelInfo))
     sig("convnet_hip_profile_enable", None, I)
     sig("convnet_hip_profile_report", ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t)
+    sig("convnet_hip_probe_matrix_pipe", I, I, ctypes.c_double, ctypes.POINTER(ctypes.c_double))
     # data-parallel exchange (csrc/comm.hip)
     sig("convnet_hip_comm_unique_id", I, ctypes.c_char_p)
     sig("convnet_hip_comm_init", I, I, I, ctypes.c_char_p)
@@ -231,3 +232,13 @@ def GetStringError(err_code):
     if err_code == -3:
         msg += lib.get_last_cuda_error().decode()
     return msg
+
+
+def probe_matrix_pipe(random_operands=True, seconds=0.05):
+    """{bf16_tflops, tflops_eq, ghz_counter, ghz_issue}: the sustained rate of a pure v_mfma_f32_32x32x16_bf16 stream on this chip
+    (csrc/probe.hip: one wave per SIMD, register operands, nothing else issued) — the power-limited ceiling of the bf16-split kernels."""
+    out = (ctypes.c_double * 4)()
+    rc = lib.convnet_hip_probe_matrix_pipe(1 if random_operands else 0, float(seconds), out)
+    if rc != 0:
+        raise RuntimeError(f"convnet_hip_probe_matrix_pipe failed: {rc}")
+    return {"bf16_tflops": out[0], "tflops_eq": out[1], "ghz_counter": out[2], "ghz_issue": out[3]}

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libconvnet_hip.so")
-SOURCES = ["state.hip", "gather_gemm.hip", "patch_gemm.hip", "wgrad_wide.hip", "fewc_conv.hip", "pool_norm.hip", "elementwise.hip", "input_staging.hip", "comm.hip", "rccl_abi_check.hip"]
+SOURCES = ["state.hip", "gather_gemm.hip", "patch_gemm.hip", "wgrad_wide.hip", "fewc_conv.hip", "pool_norm.hip", "elementwise.hip", "input_staging.hip", "comm.hip", "rccl_abi_check.hip", "probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-inline-asm"]
 # Per-file additions.  patch_gemm.hip: the SLP vectoriser packs the split's fp32 subtractions into v_pk_add_f32 (+ the v_mov / s_nop
 # that feed them) — fewer instructions on paper, but beside MFMAs a packed fp32 op costs more issue time than the two plain ones

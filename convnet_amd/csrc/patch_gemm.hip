@@ -25,6 +25,13 @@
 
 #include "gather_gemm.h"
 
+#ifndef CONVNET_GPV_LDS_MAP
+#define CONVNET_GPV_LDS_MAP 0   // gpv_kernel: 0 = filter ring, then the two slabs, then the dump slot; 1 = ring stages and slabs interleaved
+#endif
+#ifndef CONVNET_GPV_FILT_LATE
+#define CONVNET_GPV_FILT_LATE 1   // gpv_kernel: the filter pieces in the split-free steps of columns 1 and 2 (0: under column 0, as gpw_kernel)
+#endif
+
 namespace chip {
 
 // One pass over an activation / derivative tensor (CHWN fp32, C % 16 == 0, N % 64 == 0): exact three-way bf16 split into the layout
@@ -1149,8 +1156,18 @@ __global__ __launch_bounds__(256, 1) void gpv_kernel(const GGParams pin, const G
   constexpr unsigned A_WAVE = A_STAGE * 4 / WC;   // bytes of a filter chunk per wave: 3 072 (MT = 4), 2 304 (MT = 3)
   static_assert(MT == 4 || MT == 3, "a wave's share of a filter chunk is three pieces, or two and a quarter");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#if CONVNET_GPV_LDS_MAP == 1
+  // filter stage 0 | slab 0 | filter stage 1 | slab 1 | filter stage 2 | dump slot
+  constexpr int A_STRIDE = A_STAGE + SLAB, B_STRIDE = A_STAGE + SLAB;
+  float* As = smem;
+  float* Bs = smem + A_STAGE;
+  float* const dump_slot = smem + STA * A_STAGE + 2 * SLAB;
+#else
+  constexpr int A_STRIDE = A_STAGE, B_STRIDE = SLAB;
   float* As = smem;                   // [STA][A_STAGE]
   float* Bs = smem + STA * A_STAGE;   // [2][SLAB], then a 4 KB dump slot
+  float* const dump_slot = smem + STA * A_STAGE + 2 * SLAB;
+#endif
 
   const GGParams& p = pin;
   GGTile T;
@@ -1277,8 +1294,13 @@ __global__ __launch_bounds__(256, 1) void gpv_kernel(const GGParams pin, const G
     const size_t a_chunk_bytes = (size_t)p.row_tiles * (6 * ROWS * 16);
     const unsigned lds_a = lds_addr(As) + A_WAVE * wave;
     const unsigned lds_b = lds_addr(Bs);
-    const unsigned lds_dump = lds_b + 2u * SLAB * 4u;
+    const unsigned lds_dump = lds_addr(dump_slot);
 
+#ifdef CONVNET_DIAG
+    // timing diagnostics (results wrong), CONVNET_GPP_DIAG: 1 = no slot loads after the prologue, 2 = no filter loads after it, 4 = no dump loads
+    const int dg = p.prio, dg_slot = 1 - (dg & 1), dg_filt = 1 - ((dg >> 1) & 1), dg_nodump = (dg >> 2) & 1;
+    int dg_ring_dump = 0;   // (32: set behind the prologue, which then fills all three ring stages)
+#endif
     // Everything below steps with selects between values that are already computed (gpw_kernel's rules: no lazily evaluated side, 0/1
     // flags and masks instead of booleans, differences instead of selected addresses).
     // filter iterator, two chunks ahead of the MFMAs: tap slot i of group g of tap row a of channel block cb is filter chunk
@@ -1289,16 +1311,39 @@ __global__ __launch_bounds__(256, 1) void gpv_kernel(const GGParams pin, const G
     const ptrdiff_t a_x1 = ng == 2 ? (ptrdiff_t)a_chunk_bytes * (TX + gb00 - (gb01 + (cnt1 - 1) * dstep) - dstep) : a_x0;
     const ptrdiff_t a_cbs_x = (ptrdiff_t)a_chunk_bytes * (TYX - (a_hi - a_lo + 1) * TX);
     const char* a_ptr = abase0 + a_chunk_bytes * (size_t)(cb_beg * TYX + (a_lo + r_beg) * TX + (g_beg ? gb01 : gb00));   // wave-uniform
+#ifdef CONVNET_DIAG
+    if (dg & 8) a_ptr += (size_t)((blockIdx.x >> 3) & 7) * 4096;     // every block of an XCD group reads its filter chunks 4 KB further on (wrong data, same amount)
+    if (dg & 16) a_ptr += (size_t)((blockIdx.x >> 3) & 7) * 256;     // ... 256 B further on
+#endif
     int A_i = 0, A_g = g_beg, A_cnt = g_beg ? cnt1 : cnt0, A_r = r_beg, A_left = nchunks;
-    unsigned lds_f0 = lds_a, lds_f1 = lds_a + A_STAGE * 4u, lds_f2 = lds_a + 2u * A_STAGE * 4u;   // the ring stage to fill next first
+    unsigned lds_f0 = lds_a, lds_f1 = lds_a + A_STRIDE * 4u, lds_f2 = lds_a + 2u * A_STRIDE * 4u;   // the ring stage to fill next first
     const char* a_cur = nullptr;
     unsigned a_lds = 0;
     auto issue_a_addr = [&]() __attribute__((always_inline)) {
       a_cur = uniform_ptr(a_ptr);
       a_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_f0);
+#ifdef CONVNET_DIAG
+      // 32: the filter pieces land in the dump slot; 64: they read the zero page (every lane the same 16 bytes); 128: always the range's first chunk
+      {
+        const unsigned m32 = 0u - (unsigned)dg_ring_dump;
+        a_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(a_lds ^ ((a_lds ^ lds_dump) & m32)));
+        const ptrdiff_t m64 = -(ptrdiff_t)((dg >> 6) & 1), m128 = -(ptrdiff_t)((dg >> 7) & 1);
+        const char* q = a_cur + ((abase0 - a_cur) & m128);
+        q = q + ((zero_page - q) & m64);
+        a_cur = uniform_ptr(q);
+      }
+#endif
     };
     auto issue_a_piece = [&](auto J) __attribute__((always_inline)) {
       constexpr int j = decltype(J)::value;
+#ifdef CONVNET_DIAG
+      if constexpr (MT == 4) {
+        const unsigned m32 = 0u - (unsigned)dg_ring_dump, m64 = 0u - ((unsigned)(dg >> 6) & 1u);
+        lds_dma_piece_if_rfl<j>(sgpr(dg_filt), a_lane & ~m64, uniform_ptr(a_cur - ((ptrdiff_t)(1024 * j) & -(ptrdiff_t)((dg >> 6) & 1))),
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(a_lds - ((1024u * j) & m32))));
+        return;
+      }
+#endif
       if constexpr (MT == 3 && j == 2) lds_dma_quarter_rfl<j>(a_lane, a_cur, a_lds);
       else lds_dma_piece_rfl<j>(a_lane, a_cur, a_lds);
     };
@@ -1351,7 +1396,7 @@ __global__ __launch_bounds__(256, 1) void gpv_kernel(const GGParams pin, const G
     };
     const ptrdiff_t d4 = (ptrdiff_t)(4 * ch_bytes) - 1024;   // four channel planes on, minus the 1 KB the immediate offset adds
     struct SlotIssue {
-      unsigned so, voff, ld, real;   // real: 0 / 1
+      unsigned so, voff, ld, real, none;   // real, none: 0 / 1
       const char *p0, *p1, *p2, *p3;
     } si;
     auto slot_kind = [&](int sl, unsigned ldbuf, unsigned soff, int enable) __attribute__((always_inline)) {
@@ -1361,6 +1406,7 @@ __global__ __launch_bounds__(256, 1) void gpv_kernel(const GGParams pin, const G
       const unsigned is_no = 1u - min(si.so + 1u, 1u), is_zero = 1u - min(si.so + 2u, 1u);   // so == kNoSlot, so == kZeroSlot
       const unsigned none = (1u - (unsigned)enable) | neg | is_no;
       si.real = (1u - none) & (1u - is_zero);
+      si.none = none;
       const unsigned ldr = ldbuf + (unsigned)slc * 4096u;
       si.ld = ldr ^ ((ldr ^ lds_dump) & (0u - none));                        // none ? dump : slot
       si.voff = lane_off_raw & (0u - si.real);
@@ -1380,17 +1426,24 @@ __global__ __launch_bounds__(256, 1) void gpv_kernel(const GGParams pin, const G
     };
     auto slot_piece = [&](auto J) __attribute__((always_inline)) {
       constexpr int j = decltype(J)::value;
+#ifdef CONVNET_DIAG
+      lds_dma_piece_if_rfl<j>(sgpr(dg_slot & (1 - (dg_nodump & (int)si.none))), si.voff, j == 0 ? si.p0 : j == 1 ? si.p1 : j == 2 ? si.p2 : si.p3, (unsigned)__builtin_amdgcn_readfirstlane((int)si.ld));
+      return;
+#endif
       lds_dma_piece_rfl<j>(si.voff, j == 0 ? si.p0 : j == 1 ? si.p1 : j == 2 ? si.p2 : si.p3, (unsigned)__builtin_amdgcn_readfirstlane((int)si.ld));
     };
     auto slot_piece_if = [&](int on, auto J) __attribute__((always_inline)) {
       constexpr int j = decltype(J)::value;
+#ifdef CONVNET_DIAG
+      on = sgpr(on & dg_slot & (1 - (dg_nodump & (int)si.none)));
+#endif
       lds_dma_piece_if_rfl<j>(on, si.voff, j == 0 ? si.p0 : j == 1 ? si.p1 : j == 2 ? si.p2 : si.p3, (unsigned)__builtin_amdgcn_readfirstlane((int)si.ld));
     };
 
     // ================================ consumer state ================================
     const int boff = S_l * 1024 + lh * 64 + NTC * (li & 15);   // floats inside a slab: slot base + k-row lh + first image
     auto load_a = [&](int st, Split8 (&fa)[MT]) __attribute__((always_inline)) {
-      const u32x4* ap = reinterpret_cast<const u32x4*>(As + st * A_STAGE) + lh * ROWS + li;
+      const u32x4* ap = reinterpret_cast<const u32x4*>(As + st * A_STRIDE) + lh * ROWS + li;
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         fa[t].h = ap[t * 32];
@@ -1402,14 +1455,14 @@ __global__ __launch_bounds__(256, 1) void gpv_kernel(const GGParams pin, const G
     unsigned bufsel = 0;   // 0 / 1: the slab buffer the MFMAs read
     f32x4 bv[8];
     auto read_b = [&]() __attribute__((always_inline)) {
-      const float* bs = Bs + bufsel * SLAB + ti * 1024 + boff;
+      const float* bs = Bs + bufsel * B_STRIDE + ti * 1024 + boff;
 #pragma unroll
       for (int j = 0; j < 8; ++j) bv[j] = ld4(bs + 2 * j * 64);
     };
     // the wave's three slots of a slab rotate with its slot loads: one per chunk of a 3-chunk superchunk, two and one in a 2-chunk one
     int o0 = my_ord[0], o1 = my_ord[1], o2 = my_ord[2];
     auto next_slot_kind = [&](int on) __attribute__((always_inline)) {   // on = 0: no slot this time — a dump load's description, no rotation
-      slot_kind(o0, lds_b + (bufsel ^ 1u) * (SLAB * 4u), slot_desc(a_lo + B_r, B_g), on & (int)((unsigned)(sc + 1 - sc_end) >> 31));   // sc + 1 < sc_end
+      slot_kind(o0, lds_b + (bufsel ^ 1u) * (B_STRIDE * 4u), slot_desc(a_lo + B_r, B_g), on & (int)((unsigned)(sc + 1 - sc_end) >> 31));   // sc + 1 < sc_end
       const int m = -on, r0 = o0 ^ o1, r1 = o1 ^ o2, r2 = o2 ^ o0;
       o0 ^= r0 & m;   // on: (o0, o1, o2) <- (o1, o2, o0)
       o1 ^= r1 & m;
@@ -1441,6 +1494,16 @@ __global__ __launch_bounds__(256, 1) void gpv_kernel(const GGParams pin, const G
     }
     issue_a();
     issue_a();   // (two ahead)
+#ifdef CONVNET_DIAG
+    if (dg & 32) {   // real data in the third stage too, then no more writes into the ring
+      const char* keep_p = a_ptr;
+      const int k0 = A_i, k1 = A_g, k2 = A_cnt, k3 = A_r, k4 = A_left;
+      issue_a();
+      a_ptr = keep_p; A_i = k0; A_g = k1; A_cnt = k2; A_r = k3; A_left = k4;
+      const unsigned f = lds_f2; lds_f2 = lds_f1; lds_f1 = lds_f0; lds_f0 = f;
+      dg_ring_dump = 1;
+    }
+#endif
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
     __syncthreads();
 
@@ -1496,6 +1559,46 @@ __global__ __launch_bounds__(256, 1) void gpv_kernel(const GGParams pin, const G
       for (int u = 0; u + 1 < NTC; ++u) {
         Split8& fn = fb[(u + 1) & 1];
         const Split8& fc = fb[u & 1];
+#if CONVNET_GPV_FILT_LATE
+        // Where a staging load sits matters more than how many there are (measured, profiles/r06_gpv_kernel.md: with the filter pieces
+        // under column 0 — in the wake of the chunk's twenty ds_read_b128 — they cost ~230 cycles each and the kernel 15 %; the slot
+        // pieces under column 1 ~20): column 0 carries bookkeeping only, the slot pieces sit under columns 1 and 2, the filter pieces
+        // in the split-free steps 4 and 5 of columns 1 and 2.
+        if (u == 2) slot_piece_if(two, K0{});
+        split_pair(u + 1, 0, fn);
+        if (u == 1) slot_piece(K0{});
+        mac_step(K0{}, fa, fc, u);
+        if (u == 2) slot_piece_if(two, K1{});
+        split_pair(u + 1, 1, fn);
+        if (u == 1) slot_piece(K1{});
+        mac_step(K1{}, fa, fc, u);
+        if (u == 2) slot_piece_if(two, K2{});
+        split_pair(u + 1, 2, fn);
+        if (u == 0) next_slot_kind(1);
+        if (u == 1) slot_piece(K2{});
+        mac_step(K2{}, fa, fc, u);
+        if (u == 2) slot_piece_if(two, K3{});
+        split_pair(u + 1, 3, fn);
+        if (u == 0) slot_addr(slab_src);
+        if (u == 1) slot_piece(K3{});
+        mac_step(K3{}, fa, fc, u);
+        if (u == 0) issue_a_addr();
+        if (u == 1) {
+          issue_a_piece(K0{});
+          next_slot_kind(two);
+        }
+        if (u == 2) {
+          issue_a_piece(K2{});
+          advance();
+        }
+        mac_step(K4{}, fa, fc, u);
+        if (u == 1) {
+          issue_a_piece(K1{});
+          slot_addr(slab_src);
+        }
+        if (u == 2) issue_a_step();
+        mac_step(K5{}, fa, fc, u);
+#else
         if (u == 2) slot_piece_if(two, K0{});
         split_pair(u + 1, 0, fn);
         if (u == 0) issue_a_addr();
@@ -1526,6 +1629,7 @@ __global__ __launch_bounds__(256, 1) void gpv_kernel(const GGParams pin, const G
           slot_addr(slab_src);
         }
         mac_step(K5{}, fa, fc, u);
+#endif
       }
       CHIP_PIN_SPLIT8(fb[(NTC - 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
@@ -1706,7 +1810,7 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
   {
     // filter bank -> [chunk][row tile][plane, k-group][ROWS rows] bf16 planes
     const size_t welems = (size_t)CB * p.TYX * RT * ROWS * 16;
-    u32x4* ap = static_cast<u32x4*>(workspace_aux(welems * 6));
+    u32x4* ap = static_cast<u32x4*>(workspace_aux(welems * 6 + (CHIP_DIAG_KNOB("CONVNET_GPP_DIAG", 0) ? 65536 : 0)));
     filter_planes_rt_launch(bank, ap, p.TYX, ROWS, op);
     p.A = reinterpret_cast<const float*>(ap);
     p.apre = 1;
@@ -1815,7 +1919,10 @@ void patch_run(GGParams& p, size_t dst_elems, const char* op, double flops, cons
 // fills it for the tap-major pre-split path (KC = filters, apre, dir = -1, ssx = 1); the classes carry their banks as bf16 planes per
 // row tile of wide_rows(R) rows (gg_tile_rows gives the same height).  Fills ncols / col_tiles / tile_end.  False: not this shape.
 bool patch_classes_ok(const GGParams& base, const GGClassTable& ct) {
-  if (patch_mode() < 3 || matrix_path() == 0 || !base.apre || base.KC <= 0 || base.KC % BK != 0) return false;
+  // Mode 4 only (parity tests, A/B runs).  Measured on the MI355X (profiles/r06_gpv_kernel.md): conv2's input gradient runs 1 273 us here against
+  // 1 173 on ggp_kernel<1,4,3,64> — an 8-pixel tile cannot leave out the border taps of its edge pixels (7 % more MFMA work than the one-pixel
+  // tiles, which skip them per pixel), and the 96-row build issues 6.6 other instructions per MFMA.  The default keeps ggp_kernel.
+  if (patch_mode() < 4 || matrix_path() == 0 || !base.apre || base.KC <= 0 || base.KC % BK != 0) return false;
   if (base.N % 64 != 0 || base.R <= 64 || base.dir >= 0 || base.ssx != 1 || base.ssy != 1) return false;
   if ((size_t)base.SH * base.SW * base.N >= (size_t(1) << 28)) return false;
   if (ct.n < 1) return false;
@@ -1832,7 +1939,7 @@ void patch_run_classes(GGParams& p, GGClassTable& ct, const char* op, double flo
   p.ncols = 0;
   p.row_tiles = divup(p.R, ROWS);
   p.zero = zero_page();
-  p.prio = 0;
+  p.prio = CHIP_DIAG_KNOB("CONVNET_GPP_DIAG", 0);
   p.splits = 1;
   p.chunks_per_split = 1 << 24;
   p.partial = nullptr;

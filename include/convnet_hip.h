@@ -364,6 +364,12 @@ void convnet_hip_last_kernel_info(ConvnetHipKernelInfo* out);
  * (flops = algorithmic work; executed = MFMA work issued, larger for dgrad gathers that run border taps on the zero page). */
 void convnet_hip_profile_enable(int on);
 size_t convnet_hip_profile_report(char* buf, size_t cap);
+/* What the chip sustains on the instruction the default GEMM kernels execute (v_mfma_f32_32x32x16_bf16, six per fp32 product block),
+ * with nothing else in the way: one wave per SIMD, sixteen accumulators, register operands — the h / m / l planes of N(0,1) values
+ * (random_operands = 1) or zeros (0) — for about `seconds`.  The part clocks to its power budget, so this is the ceiling a kernel of
+ * these instructions has on this box, beside the nominal 2.5 PFLOP/s (csrc/probe.hip).  out4 = {executed bf16 TFLOP/s, the same / 6 =
+ * algorithmic fp32 TFLOP/s, GHz by the shader-cycle counter over wall time, GHz the MFMA issue rate implies}.  Returns 0 or an error code. */
+int convnet_hip_probe_matrix_pipe(int random_operands, double seconds, double* out4);
 
 /* ---- data-parallel gradient exchange (csrc/comm.hip): replaces ConvNet::Accumulate + ConvNet::Broadcast ------------------
  * Reference (src/convnet.cc:407-450, behind USE_MPI): after Bprop the whole flat gradient goes device -> host, rank 0

@@ -431,7 +431,7 @@ int main(int argc, char** argv) {
   }
   if (what == "gpv" || all || quick) {   // gpv_kernel: tap rows in groups of three and two (patch_gemm.hip)
     fprop_case(Geo{64, 16, 23, 23, 96, 5, 5, 2, 2, 0}, 4, "gpv");      // conv2's form ({0,2,4} / {1,3}) on the 96-row build: 10-wide output rows, ragged last tile
-    abi_conv_case(Geo{64, 96, 19, 19, 16, 5, 5, 2, 2, 0}, "down", 3);  // conv2's input gradient: classes of 3x3, 3x2, 2x3, 2x2 taps in one launch, 96 rows
+    abi_conv_case(Geo{64, 96, 19, 19, 16, 5, 5, 2, 2, 0}, "down", 4);  // conv2's input gradient: classes of 3x3, 3x2, 2x3, 2x2 taps in one launch, 96 rows
     if (!quick) {
       fprop_case(Geo{64, 16, 21, 21, 130, 5, 5, 2, 2, 0}, 4, "gpv");   // 128-row build, partial second row tile, 9-wide rows: a wrap in almost every tile
       fprop_case(Geo{128, 32, 19, 19, 96, 5, 5, 2, 2, 0}, 4, "gpv");   // two image blocks, two channel blocks
@@ -439,8 +439,8 @@ int main(int argc, char** argv) {
       fprop_case(Geo{64, 16, 20, 20, 128, 4, 4, 2, 2, 1}, 4, "gpv");   // 4 x 4 stride 2: groups of two and two
       fprop_case(Geo{64, 16, 10, 10, 128, 2, 2, 1, 1, 0}, 4, "gpv");   // one group of two: every superchunk is (two slots, one slot)
       fprop_case(Geo{64, 16, 9, 9, 72, 3, 3, 1, 1, 1}, 4, "gpv");      // gpw_kernel's 3 x 3 stride-1 case on the 96-row build
-      abi_conv_case(Geo{64, 132, 17, 21, 16, 5, 5, 2, 2, 2}, "down", 3);   // 128-row build, two row tiles, padded: classes start at different pixels
-      abi_conv_case(Geo{64, 96, 20, 20, 16, 4, 4, 2, 2, 1}, "down", 3);    // four classes of 2 x 2 taps
+      abi_conv_case(Geo{64, 132, 17, 21, 16, 5, 5, 2, 2, 2}, "down", 4);   // 128-row build, two row tiles, padded: classes start at different pixels
+      abi_conv_case(Geo{64, 96, 20, 20, 16, 4, 4, 2, 2, 1}, "down", 4);    // four classes of 2 x 2 taps
     }
   }
   if (what == "gpvtail") {   // 13 tiles on an 8-slot "chip", the last round's 5 tiles cut in 3 K-ranges (ranges begin inside a tap row's groups)
