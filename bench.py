@@ -6,12 +6,16 @@ exchange]) of the AlexNet-class model (BASELINE.json metric) on N MI355X GPUs of
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU.  Each rank trains a full replica on its own synthetic batch of --batch images
-(weak scaling, exactly the reference's train_convnet_data_parallel semantics: every MPI rank reads
-its own batch of `batch_size` and the gradients are averaged, src/convnet.cc:407-450); with
---global-batch G the ranks share G images per step (strong scaling, G/N each).  Rank 0 prints
-ONE JSON line.  `value` = images processed by all ranks / max-over-ranks wall time of K steps,
-bracketed by barrier + torch.cuda.synchronize().
+One process per GPU, each rank a full replica on its own synthetic batch, gradients averaged over RCCL
+(the reference's train_convnet_data_parallel semantics, src/convnet.cc:407-450).  With N > 1 the headline
+run is BASELINE's configuration 4 — AlexNet at a GLOBAL batch of 256 split over the ranks (256/N each:
+`scaling` "strong", `config4_value` = `value`), with the weak run (--batch images on EVERY rank) nested
+as `weak` and `exchange_ms_exposed` = the step with the exchange minus the same step without it;
+--weak swaps the roles, --global-batch G sets the global batch.  Rank 0 prints ONE JSON line.  `value` =
+images processed by all ranks / max-over-ranks wall time of K steps, bracketed by barrier +
+torch.cuda.synchronize().  The weight gradients run on a second HIP stream by default (--no-overlap-wgrad: one
+stream); `one_stream_ms_per_step` / `two_stream_ms_per_step` time the same K steps both ways after the headline
+region, without kernel timers, so that what the second stream is worth on the box is on every line.
 
 Extra objects on the line:
   roofline      dominant MFMA kernel: algorithmic flops / HIP-event time measured per launch inside
@@ -23,12 +27,15 @@ Extra objects on the line:
                 the fp32 matrix instruction's 157.3 TFLOP/s.  No fraction on the line can exceed 1; the ratio to the
                 fp32-instruction peak travels only as the labelled extra `vs_fp32_instruction_peak`.  Also
                 `model_frac` = whole-step algorithmic flops / step time / the same peak, and per-family rows under
-                `families`.  With the second stream on (default) a launch's duration includes what the co-running
-                kernel of the other stream took — `roofline.one_stream` gives the dominant kernel's rate without a
-                neighbour.
+                `families` (from four extra one-stream steps with every launch timed: additive, they sum to at most the
+                one-stream step).  `power_ceiling`: what THIS chip sustains on a pure stream of the executed instruction
+                with N(0,1) operand planes, measured in the run by the library's probe (csrc/probe.hip) — the part clocks
+                to its power budget, ~0.74 of the nominal peak; `frac` stays against the nominal 416.7,
+                `frac_of_power_ceiling` travels beside it.
   fp32_mfma_path  the same step with every GEMM kernel on v_mfma_f32_32x32x2_f32 instead (--matrix-path fp32),
-                timed in this process right after the main run (rank 0, N=1 only): the number to read if the
-                bf16-split products are not accepted as fp32 arithmetic.
+                timed in this process right after the main run (rank 0, N=1 only), with its OWN `roofline` object
+                (dominant kernel, `frac` against the fp32 instruction's 157.3 TFLOP/s, `all_mfma_kernels`): the numbers
+                to read if the bf16-split products are not accepted as fp32 arithmetic.
   cpu_baseline  the reference's own CPU path (oracle/_ref, eigenmat+CPUMatrix compiled unmodified)
                 — or the C port if that build is absent — running the same model's training step
                 on a bounded sample (N=6 images, 1 step, ~13 s), rank 0, N=1 only.
@@ -65,6 +72,8 @@ def _same_kernel(bench_name, prof_name):
     flat = prof_name.replace(" ", "")
     if wb == "gpw_kernel":
         return "gpw_kernel(" in flat or flat.endswith("gpw_kernel") or "gpw_kernel<" in flat
+    if wb == "gpv_kernel":   # "gpv_kernel<128x512,split,raw>" / "<96x512,...>" are chip::gpv_kernel<4> / <3>
+        return ("gpv_kernel<4>" in flat and "128x512" in wa) or ("gpv_kernel<3>" in flat and "96x512" in wa)
     if wb == "gfc_kernel":   # "gfc_kernel<96x128,split>" is chip::gfc_kernel(chip::gfc::Params)
         return "gfc_kernel<" in flat or "gfc_kernel(" in flat or flat.endswith("gfc_kernel")   # gfc_kernel<RELU>
     if wb == "wgw_kernel":
@@ -124,7 +133,7 @@ def live_pmc_traffic(kernel, args):
     env = dict(os.environ, TMPDIR="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--batch", str(args.batch), "--model", args.model,
              "--matrix-path", args.matrix_path, "--no-cpu-baseline", "--no-ref-host", "--no-other-path", "--no-kernel-timers", "--no-live-traffic"]
-    child += (["--unfused"] if args.unfused else []) + (["--no-overlap-wgrad"] if args.no_overlap_wgrad else []) + \
+    child += ["--no-power-probe", "--no-two-stream-leg"] + (["--unfused"] if args.unfused else []) + (["--no-overlap-wgrad"] if args.no_overlap_wgrad else []) + \
              (["--side-stream-update"] if args.side_stream_update and not args.no_side_stream_update else [])
     sums = {}
     try:
@@ -173,6 +182,47 @@ def kernel_peak(name):
     """Peak of the pipe a GEMM kernel family executes on, in ALGORITHMIC fp32 TFLOP/s: the bf16-split builds (",split" in the name)
     issue SPLIT_PRODUCTS bf16 MFMA flops per algorithmic flop on the 2.5 PFLOP/s dense bf16 pipe; the others use the fp32 instruction."""
     return PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS if ",split" in name else PEAK_FP32_MATRIX_TFLOPS
+
+
+def family_table(rows, steps):
+    """{family: launches / ms per step, rate and fraction of ITS roofline} from kernel-timer rows of `steps` fully timed steps"""
+    fam = {}
+    for r in rows:
+        f = fam.setdefault(r["kernel"], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "executed": 0.0})
+        for k in ("launches", "ms", "flops", "bytes", "executed"):
+            f[k] += r[k]
+    return {k: {"launches_per_step": v["launches"] / steps, "ms_per_step": round(v["ms"] / steps, 4),
+                **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                    "executed_tflops": round(v["executed"] / (v["ms"] * 1e-3) / 1e12, 2),
+                    "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / kernel_peak(k), 4)} if v["flops"] > 0 else
+                   {"gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                    "frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})}
+            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] > 0}
+
+
+def path_roofline(rows, steps):
+    """A roofline object from `steps` fully timed one-stream steps (every launch alone on the chip): the MFMA family with the most time,
+    its algorithmic rate against the peak of the pipe it executes on, every MFMA family priced the same way, the per-family table."""
+    fam = {}
+    for r in rows:
+        if r["flops"] > 0:
+            f = fam.setdefault(r["kernel"], {"launches": 0, "ms": 0.0, "flops": 0.0})
+            for k in ("launches", "ms", "flops"):
+                f[k] += r[k]
+    if not fam:
+        return None
+    dom_name = max(fam, key=lambda k: fam[k]["ms"])
+    dom = fam[dom_name]
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    all_ms = sum(v["ms"] for v in fam.values())
+    all_ideal_ms = sum(v["flops"] / (kernel_peak(k) * 1e12) * 1e3 for k, v in fam.items())
+    return {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": round(kernel_peak(dom_name), 2), "unit": "TFLOP/s",
+            "frac": round(achieved / kernel_peak(dom_name), 4), "flops_per_launch": dom["flops"] / dom["launches"],
+            "avg_launch_ms": round(dom["ms"] / dom["launches"], 4), "launches": dom["launches"], "sampled_steps": steps,
+            "clock": "HIP events, one stream: every launch alone on the chip",
+            "all_mfma_kernels": {"achieved": round(sum(v["flops"] for v in fam.values()) / (all_ms * 1e-3) / 1e12, 2),
+                                 "frac": round(all_ideal_ms / all_ms, 4), "ms_per_step": round(all_ms / steps, 3)},
+            "families": family_table(rows, steps)}
 
 
 def one_stream_fields(rows, kernel):
@@ -319,9 +369,18 @@ def main():
                          "with round 5's kernels, which own their CUs, it costs 0.2 ms (9.46 vs 9.65 ms, profiles/r05_stream_configs.txt): off")
     ap.add_argument("--no-side-stream-update", action="store_true", help="(the default now; accepted for older command lines)")
     ap.add_argument("--no-overlap-wgrad", action="store_true",
-                    help="every edge's weight gradient on the main stream instead of on a second stream beside the rest of the backward "
-                         "pass (bit-identical either way; measured 11.47 -> 11.23 ms/step)")
-    ap.add_argument("--timer-every", type=int, default=4, help="steps between kernel-timer (HIP event) sampled steps")
+                    help="every edge's weight gradient on the main stream instead of on a second HIP stream beside the rest of the backward pass "
+                         "(bit-identical either way).  Round 6, same-call legs without kernel timers on two gpurun calls: two streams 9.44-9.51 ms, one "
+                         "stream 9.58 (profiles/r06_stream_legs.txt) — the second stream stays the default, and BOTH legs travel on every line "
+                         "(`one_stream_ms_per_step`, `two_stream_ms_per_step`)")
+    ap.add_argument("--overlap-wgrad", action="store_true", help="(the default; accepted for symmetry)")
+    ap.add_argument("--no-two-stream-leg", action="store_true", help="skip the extra untimed-by-events runs of the same steps on one / two streams")
+    ap.add_argument("--weak", action="store_true",
+                    help="with --gpus N > 1: --batch images on EVERY rank as the headline run (weak scaling).  Default for N > 1 is "
+                         "BASELINE's configuration 4 — a GLOBAL batch of 256 split over the ranks — with the weak run nested as `weak`")
+    ap.add_argument("--timer-every", type=int, default=10,
+                    help="steps between kernel-timer (HIP event) sampled steps of the timed region (a sampled step costs ~0.6 ms of event packets: every "
+                         "10th step = 0.06 ms per step; the fully timed one-stream steps behind the region carry the per-family table)")
     ap.add_argument("--no-kernel-timers", action="store_true", help="diagnostic: no per-launch HIP events (roofline fields empty)")
     ap.add_argument("--staged-input", action="store_true", help="GPU-resident 256x256 chunk + crop/flip/transpose staging per batch instead of pre-staged batches")
     ap.add_argument("--unfused", action="store_true", help="issue the reference's unfused Matrix-call sequence")
@@ -348,6 +407,7 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="skip the two rocprofv3 PMC child passes that measure `roofline.traffic` (rank 0, 1 GPU only; ~25 s); the figure "
                          "is then read from the committed passes under profiles/")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip `roofline.power_ceiling` (two 0.05 s runs of the library's matrix-pipe probe)")
     ap.add_argument("--no-ref-host", action="store_true",
                     help="skip the `ref_host` leg (the reference's own unmodified C++ ConvNet::TrainOneBatch loop linked to this library, "
                          "tools/ref_host_bench.py, timed in a child process after the product run; rank 0, 1 GPU only)")
@@ -377,6 +437,9 @@ def main():
     if world != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; nothing was run\n")
         sys.exit(2)
+    # N > 1 without an explicit choice: SURVEY 8(d) config 4 (AlexNet at a GLOBAL batch of 256, src/convnet.cc:429-431) is the headline
+    if world > 1 and args.global_batch == 0 and not args.weak and args.model == "alexnet" and 256 % world == 0 and not args.staged_input:
+        args.global_batch = 256
     strong = args.global_batch > 0
     if strong:
         assert args.global_batch % world == 0, f"--global-batch {args.global_batch} does not divide over {world} ranks"
@@ -468,12 +531,14 @@ def main():
 
     dt = max_over_ranks(dt)
 
-    # With the weight gradients / optimizer steps on a second stream, kernels of the two streams share the chip, so a launch's
-    # event (and rocprofv3) duration includes what its neighbour took.  Four more steps on ONE stream, every launch timed, give the
-    # dominant kernel's undisturbed rate beside the one measured in the timed region (every rank runs them: collectives inside).
-    prof_one_stream, dt_one_stream = None, None
+    # Four more steps on ONE stream with every launch timed: each kernel alone on the chip, so the per-family times are additive (the
+    # `families` table) and the dominant kernel's rate is undisturbed.  When the timed region itself ran on one stream (the default since
+    # round 6) this only adds fully sampled steps; with --overlap-wgrad a launch's event span in the timed region includes what its
+    # neighbour on the other stream took.  Every rank runs them (collectives inside).
+    prof_one_stream, dt_one_stream, dt_two_stream = None, None, None
     side_update = args.side_stream_update and not args.no_side_stream_update
-    if (not args.no_overlap_wgrad or side_update) and not args.no_kernel_timers:
+    two_main = (not args.no_overlap_wgrad) or side_update
+    if not args.no_kernel_timers:
         keep = (net.overlap_wgrad_, net.overlap_update_)
         net.overlap_wgrad_, net.overlap_update_ = False, False
         net.TrainOneBatch()
@@ -484,10 +549,17 @@ def main():
         sync_all()
         _lib.profile_enable(False)
         prof_one_stream = _lib.profile_report()
-        # ... and the same K steps on one stream by the wall clock: `one_stream_ms_per_step` beside `ms_per_step` says what the
-        # second stream is worth on THIS box
-        dt_one_stream = timed_steps_of(net, args.steps, 1)
+        # the same K steps on one stream by the wall clock, WITHOUT kernel timers (the sampled event pairs of the timed region cost
+        # ~0.07 ms per step): `one_stream_ms_per_step` and `two_stream_ms_per_step` are measured alike, whichever is the headline
+        if not args.no_two_stream_leg:
+            dt_one_stream = timed_steps_of(net, args.steps, 1)
         net.overlap_wgrad_, net.overlap_update_ = keep
+    if not args.no_two_stream_leg:
+        # ... and the same K steps with the weight gradients on a second stream: what the overlap is worth on THIS box
+        keep = net.overlap_wgrad_
+        net.overlap_wgrad_ = True
+        dt_two_stream = timed_steps_of(net, args.steps, 2)
+        net.overlap_wgrad_ = keep
 
     other = None
     if world == 1 and not args.no_other_path:
@@ -502,44 +574,72 @@ def main():
             net.TrainOneBatch()
         sync_all()
         dt_other = time.perf_counter() - t1
+        prof_other = None
+        if not args.no_kernel_timers:   # four more steps on one stream, every launch timed: the other path's own roofline object
+            keep = (net.overlap_wgrad_, net.overlap_update_)
+            net.overlap_wgrad_, net.overlap_update_ = False, False
+            net.TrainOneBatch()
+            sync_all()
+            _lib.profile_enable(True)
+            for _ in range(4):
+                net.TrainOneBatch()
+            sync_all()
+            _lib.profile_enable(False)
+            prof_other = _lib.profile_report()
+            net.overlap_wgrad_, net.overlap_update_ = keep
         _lib.lib.convnet_hip_set_matrix_path(1 if args.matrix_path == "split" else 0)
         other = {"matrix_path": other_name, "value": round(args.batch * args.steps / dt_other, 2), "unit": "images/sec",
                  "ms_per_step": round(1e3 * dt_other / args.steps, 3), "steps": args.steps,
                  "model_frac": round(step_flops / (dt_other / args.steps) / 1e12 /
-                                     (PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS if other_name == "split" else PEAK_FP32_MATRIX_TFLOPS), 4)}
+                                     (PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS if other_name == "split" else PEAK_FP32_MATRIX_TFLOPS), 4),
+                 **({"roofline": path_roofline(prof_other, 4)} if prof_other else {})}
 
-    # STRONG scaling beside the weak headline, same process (a global batch of 256 split over the ranks,
-    # src/convnet.cc:429-431 semantics): the per-GPU batch 256/world with the exchange, and the same batch without it — the difference
-    # is what the exchange leaves exposed.  Only when the run itself is the weak one, on more than one rank.
-    # ranks that actually took part in the gradient exchange: the process group's size, and for the C-ABI transport the library's own
-    # communicator (convnet_hip_comm_size); 0 = no exchange (one GPU)
-    rccl_ranks = 0
-    if exchange is not None:
-        rccl_ranks = _lib.lib.convnet_hip_comm_size() if args.transport == "abi" else dist.get_world_size()
-    strong_obj = None
-    if (world > 1 or (args.strong_selftest and exchange is not None)) and not strong and args.model == "alexnet" and 256 % world == 0 and not args.staged_input:
+    # The other scaling mode beside the headline, same process, plus what the exchange leaves exposed.  Headline for N > 1 ranks is
+    # SURVEY 8(d) config 4 — a GLOBAL batch of 256 split over the ranks (src/convnet.cc:429-431 semantics) — unless --weak; the weak run
+    # (--batch images on every rank, global 256 x N) is then nested as `weak`, and vice versa (`strong` + `config4_value`).
+    # ranks that actually took part in the gradient exchange over RCCL: the NCCL process group's size, or for the C-ABI transport the
+    # library's own communicator (convnet_hip_comm_size: what ncclCommCount returned); 0 = no RCCL exchange (one GPU, or --share-device,
+    # where gloo carries it)
+    def rccl_count():
+        if exchange is None or args.share_device:
+            return 0
+        return _lib.lib.convnet_hip_comm_size() if args.transport == "abi" else (dist.get_world_size() if dist.get_backend() == "nccl" else 0)
+    rccl_ranks = rccl_count()
+    strong_obj, weak_obj, compute_only_ms = None, None, None
+    if (world > 1 or (args.strong_selftest and exchange is not None)) and args.model == "alexnet" and 256 % world == 0 and not args.staged_input:
         from convnet_amd.data_parallel import GradientExchange
-        sb = 256 // world
         exchange.Close()
-        times = {}
-        for label in ("compute_only", "with_exchange"):
-            ex2 = GradientExchange(bucket_bytes=int(args.bucket_mb * (1 << 20)), overlap=not args.no_overlap, transport=args.transport) if label == "with_exchange" else None
+
+        def leg(batch, with_exchange):
+            ex2 = GradientExchange(bucket_bytes=int(args.bucket_mb * (1 << 20)), overlap=not args.no_overlap, transport=args.transport) if with_exchange else None
             n2 = ConvNet(text, fused=not args.unfused, process_id=rank, num_processes=world, exchange=ex2,
                          overlap_update=args.side_stream_update and not args.no_side_stream_update, overlap_wgrad=not args.no_overlap_wgrad)
-            n2.SetBatchsize(sb)
-            n2.SetupDataset(SyntheticDataHandler(n2, sb, seed=2000 + rank, num_batches=2))
+            n2.SetBatchsize(batch)
+            n2.SetupDataset(SyntheticDataHandler(n2, batch, seed=2000 + rank, num_batches=2))
             n2.AllocateMemory(False)
-            times[label] = timed_steps_of(n2, args.steps, 3)
+            t = timed_steps_of(n2, args.steps, 3)
+            ranks = rccl_count() if with_exchange else 0
             if ex2 is not None:
-                strong_ranks = _lib.lib.convnet_hip_comm_size() if args.transport == "abi" else dist.get_world_size()
                 ex2.Close()
             del n2
-        strong_obj = {"scaling": "strong", "global_batch": 256, "batch_per_gpu": sb, "n_gpus": world, "steps": args.steps,
-                      "value": round(256 * args.steps / times["with_exchange"], 2), "unit": "images/sec",
-                      "ms_per_step": round(1e3 * times["with_exchange"] / args.steps, 3),
-                      "compute_only_ms_per_step": round(1e3 * times["compute_only"] / args.steps, 3),
-                      "exchange_exposed_ms": round(1e3 * (times["with_exchange"] - times["compute_only"]) / args.steps, 3),
-                      "rccl_ranks": strong_ranks}
+            return t, ranks
+        if strong:
+            t_co, _ = leg(args.batch, False)                      # the headline configuration without the exchange
+            compute_only_ms = 1e3 * t_co / args.steps
+            t_w, ranks_w = leg(256, True)                          # weak: 256 images on every rank
+            weak_obj = {"scaling": "weak", "global_batch": 256 * world, "batch_per_gpu": 256, "n_gpus": world, "steps": args.steps,
+                        "value": round(256 * world * args.steps / t_w, 2), "unit": "images/sec", "ms_per_step": round(1e3 * t_w / args.steps, 3),
+                        "rccl_ranks": ranks_w}
+        else:
+            sb = 256 // world
+            t_co, _ = leg(sb, False)
+            t_ex, strong_ranks = leg(sb, True)
+            strong_obj = {"scaling": "strong", "global_batch": 256, "batch_per_gpu": sb, "n_gpus": world, "steps": args.steps,
+                          "value": round(256 * args.steps / t_ex, 2), "unit": "images/sec",
+                          "ms_per_step": round(1e3 * t_ex / args.steps, 3),
+                          "compute_only_ms_per_step": round(1e3 * t_co / args.steps, 3),
+                          "exchange_exposed_ms": round(1e3 * (t_ex - t_co) / args.steps, 3),
+                          "rccl_ranks": strong_ranks}
 
     # every replica must hold the same parameters after the same steps (the exchange's result is identical on all ranks and the
     # optimizer is deterministic): checked on the weak run's net, reported on the line
@@ -562,6 +662,22 @@ def main():
             for k in ("launches", "ms", "flops", "bytes", "executed"):
                 f[k] += r[k]
         mfma = {k: v for k, v in fam.items() if v["flops"] > 0}
+        # What this chip sustains on the instruction the split kernels execute, nothing else in the way (csrc/probe.hip): the part clocks to
+        # its power budget, so the ceiling on real operands is below the nominal 416.7 — `frac` stays against the nominal peak, this
+        # travels beside it.  After every timed leg; rank 0.
+        power_ceiling = None
+        if args.matrix_path == "split" and not args.no_power_probe:
+            try:
+                pr, pz = _lib.probe_matrix_pipe(True, 0.05), _lib.probe_matrix_pipe(False, 0.05)
+                power_ceiling = {"tflops": round(pr["tflops_eq"], 1), "unit": "TFLOP/s (algorithmic fp32: executed bf16 / 6)",
+                                 "frac_of_peak": round(pr["tflops_eq"] / (PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS), 4),
+                                 "ghz": round(pr["ghz_issue"], 3), "ghz_shader_counter": round(pr["ghz_counter"], 3),
+                                 "zero_operands_tflops": round(pz["tflops_eq"], 1), "zero_operands_ghz": round(pz["ghz_issue"], 3),
+                                 "probe": "convnet_hip_probe_matrix_pipe (csrc/probe.hip): a pure v_mfma_f32_32x32x16_bf16 stream, one wave per SIMD, "
+                                          "16 accumulators, register operands = h/m/l planes of N(0,1) values, no memory traffic, no split "
+                                          "arithmetic, 0.05 s, measured in this run; zeros for comparison (the chip clocks to its power budget)"}
+            except Exception as e:  # noqa: BLE001 — a reported extra
+                power_ceiling = {"tflops": None, "note": f"probe failed: {e!r}"}
         roofline = None
         if mfma:
             # The dominant kernel is the MFMA family with the most time on the chip TO ITSELF: ranked by the one-stream steps (every
@@ -610,6 +726,8 @@ def main():
                    if traffic_fields.get("rocprof_avg_launch_ms") else {}),
                 "flops_per_launch": dom["flops"] / dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                 "launches": dom["launches"], "sampled_steps": timed_steps,
+                **({"power_ceiling": power_ceiling,
+                    "frac_of_power_ceiling": round(achieved / power_ceiling["tflops"], 4)} if power_ceiling and power_ceiling.get("tflops") and split_dom else {}),
                 "all_mfma_kernels": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
                                      "frac": round(all_ideal_ms / all_ms, 4),
                                      "ms_per_step": round(all_ms / timed_steps, 3)},
@@ -621,13 +739,11 @@ def main():
                              "frac": round(SPLIT_PRODUCTS * (executed if executed > 0 else achieved) / PEAK_BF16_MATRIX_TFLOPS, 4)}}
                    if split_dom else {}),
                 **one_stream_fields(prof_one_stream, dom_name),
-                "families": {k: {"launches_per_step": v["launches"] / timed_steps, "ms_per_step": round(v["ms"] / timed_steps, 4),
-                                 **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                     "executed_tflops": round(v["executed"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                     "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / kernel_peak(k), 4)} if v["flops"] > 0 else
-                                    {"gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                                     "frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})}
-                             for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
+                # per family, from the four fully timed ONE-STREAM steps (every launch alone on the chip): the ms_per_step column is
+                # additive and sums to at most the one-stream step; whatever is not event-timed (copies, host gaps) is the remainder
+                "families": family_table(prof_one_stream, 4) if prof_one_stream else family_table(prof, max(1, timed_steps)),
+                "families_source": "4 extra one-stream steps, every launch timed" if prof_one_stream else "timed region (sampled steps)",
+                "families_ms_per_step_sum": round(sum(r["ms"] for r in (prof_one_stream or prof)) / (4 if prof_one_stream else max(1, timed_steps)), 3),
                 "ops": {f'{r["kernel"]}|{r["op"]}': round(r["ms"] / timed_steps, 4) for r in sorted(prof, key=lambda r: -r["ms"])},
             }
         out = {
@@ -635,6 +751,9 @@ def main():
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "one_stream_ms_per_step": round(1e3 * dt_one_stream / args.steps, 3) if dt_one_stream else None,
+            "stream_legs_note": "one_stream / two_stream_ms_per_step: the same K steps timed after the headline region without kernel timers (weight gradients on "
+                                "the main stream / on a second HIP stream); the headline region carries sampled HIP-event pairs (~0.07 ms per step)",
+            "two_stream_ms_per_step": round(1e3 * dt_two_stream / args.steps, 3) if dt_two_stream else None,
             "host_enqueue_ms_per_step": round(1e3 * dt_enqueue / args.steps, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "rccl_ranks": rccl_ranks,
@@ -658,6 +777,13 @@ def main():
             out["strong"] = strong_obj
             # SURVEY 8(d) config 4 — AlexNet at a GLOBAL batch of 256 on N GPUs — at top level beside the weak `value` (global 256 x N)
             out["config4_value"] = strong_obj["value"]
+        if strong and args.model == "alexnet" and args.global_batch == 256:
+            out["config4_value"] = out["value"]   # the headline IS config 4
+        if compute_only_ms is not None:
+            out["compute_only_ms_per_step"] = round(compute_only_ms, 3)
+            out["exchange_ms_exposed"] = round(ms_per_step - compute_only_ms, 3)   # step with the exchange - the same step without it
+        if weak_obj is not None:
+            out["weak"] = weak_obj
         if replicas_identical is not None:
             out["replicas_identical"] = replicas_identical
         if args.share_device:

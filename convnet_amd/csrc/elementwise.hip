@@ -50,6 +50,7 @@ int map2(cudamat* out, const cudamat* a, const cudamat* b, F f) {
   if (numel(out) != n || (b && numel(b) != n)) return ERROR_INCOMPATIBLE_DIMENSIONS;
   if (n == 0) return 0;
   const bool vec = al16(out->data_device) && al16(a->data_device) && (!b || al16(b->data_device));
+  KernelTimer timer("map2_kernel", "elementwise", 0.0, 4.0 * n * (b ? 3 : 2));
   hipLaunchKernelGGL(map2_kernel<F>, dim3(blocks_for(n / 4 + 1)), dim3(kThreads), 0, stream(), out->data_device,
                      a->data_device, b ? b->data_device : nullptr, n, vec, f);
   return launch_status();
@@ -367,6 +368,9 @@ inline int rows_normlimit(float* g, float* w_in, float* w_out, float* h, int row
   float* factor = partial + (size_t)nchunks * rows;
   dim3 grid(divup(rows, 256), nchunks);
   const bool v4 = (rows & 3) == 0 && al16(w_in) && (!do_sgd || (al16(g) && al16(h)));
+  // (one timer over the three launches: the fused SGD + row-norm pass reads g, w, h, writes h, w, then re-reads and re-writes w)
+  KernelTimer timer(do_sgd ? "rows_sq_kernel<sgd> + row_scale_kernel" : "rows_sq_kernel + row_scale_kernel", do_sgd ? "sgd_normlimit" : "normlimit", 0.0,
+                    4.0 * (double)rows * cols * (do_sgd ? 7 : 3));
   if (v4) {
     const dim3 g4(divup(rows / 4, 64), nchunks);
     if (do_sgd)
@@ -563,6 +567,7 @@ int rng_launch(rnd_struct* st, float* out, const float* in, size_t n, float p, f
   ph.k1 = (unsigned)h->seed ^ (unsigned)(h->counter >> 32) ^ 0x85EBCA6Bu;
   h->counter++;
   if (n == 0) return 0;
+  KernelTimer timer(MODE == 2 ? "rng_kernel<dropout>" : MODE == 4 ? "rng_kernel<relu_dropout>" : "rng_kernel", "rng", 0.0, 4.0 * n * (in ? 2 : 1));
   hipLaunchKernelGGL(rng_kernel<MODE>, dim3(blocks_for(n / 4 + 1)), dim3(kThreads), 0, stream(), out, in, n, ph, p, val, scale);
   return launch_status();
 }
@@ -620,7 +625,7 @@ inline bool same_mat(const cudamat* a, const cudamat& b) { return a->on_device &
 // add_row_vec(T viewed as (N*M, F), bias(1, F), T) behind convUp(..., T): the shared bias of src/conv_edge.cc:145-148
 bool absorb_bias(cudamat* mat, cudamat* vec, cudamat* target) {
   PendingOp& o = pending();
-  if (o.kind != 1 || o.has_bias || o.relu || mat != target && mat->data_device != target->data_device) return false;
+  if (o.kind != 1 || o.has_bias || o.relu) return false;   // (mat and target are both checked against the parked call's target below)
   const int F = o.desc.num_output_channels;
   if (!same_mat(mat, o.m[2]) || !same_mat(target, o.m[2]) || mat->is_trans || !vec->on_device || (int)numel(vec) != F || mat->size[1] != F) return false;
   o.bias = *vec;
@@ -783,6 +788,7 @@ int softmax_ce_grad_correct(cudamat* logits, cudamat* labels, cudamat* probs, cu
   if (numel(probs) != numel(logits) || (deriv && numel(deriv) != numel(logits)) || numel(labels) != (size_t)logits->size[0])
     return ERROR_INCOMPATIBLE_DIMENSIONS;
   SoftmaxOut o{probs->data_device, deriv ? deriv->data_device : nullptr, correct_accum ? correct_accum->data_device : nullptr};
+  KernelTimer timer("softmax_rows_kernel", "softmax_ce", 0.0, 4.0 * numel(logits) * (deriv ? 3 : 2));
   hipLaunchKernelGGL(softmax_rows_kernel<32>, dim3(divup(logits->size[0], 32)), dim3(1024), 0, stream(), logits->data_device, labels->data_device, o,
                      logits->size[0], logits->size[1], deriv_scale);
   return launch_status();
@@ -795,6 +801,7 @@ int sgd_momentum_step(cudamat* grad, cudamat* param, cudamat* history, float l2_
   if (numel(grad) != n || numel(history) != n) return ERROR_INCOMPATIBLE_DIMENSIONS;
   if (n == 0) return 0;
   const bool vec = al16(grad->data_device) && al16(param->data_device) && al16(history->data_device);
+  KernelTimer timer("sgd_kernel", "sgd", 0.0, 20.0 * n);   // reads g, w, h; writes h, w (>= 20 bytes per parameter)
   hipLaunchKernelGGL(sgd_kernel, dim3(blocks_for(n / 4 + 1)), dim3(kThreads), 0, stream(), grad->data_device, param->data_device,
                      history->data_device, n, vec, l2_decay, gradient_clip, epsilon, momentum);
   return launch_status();

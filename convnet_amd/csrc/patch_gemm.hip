@@ -1634,8 +1634,13 @@ __global__ __launch_bounds__(256, 1) void gpv_kernel(const GGParams pin, const G
       CHIP_PIN_SPLIT8(fb[(NTC - 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
       // everything this wave issued before this chunk's batch (7 loads, or 11) has landed: vmcnt(7 | 11) lgkmcnt(0)
+#ifdef CONVNET_DIAG
+      if (!(dg & 512)) wait_vm_7_or_11(two);     // 512: no wait for the loads, 256: no chunk barrier (what the synchronisation costs)
+      if (!(dg & 256)) __syncthreads();
+#else
       wait_vm_7_or_11(two);
       __syncthreads();                      // ... and every other wave's; every wave has read this chunk's A and slab slots out of LDS
+#endif
       {
         const Split8& fc = fb[(NTC - 1) & 1];
         Split8& fn = fb[NTC & 1];

@@ -560,7 +560,7 @@ __global__ void rnorm_fwd_lds_kernel(const float* __restrict__ in, float* __rest
 }
 
 template <int LT>
-__global__ void rnorm_undo_lds_kernel(const float* __restrict__ dout, const float* __restrict__ in, float* __restrict__ out, size_t locs, int C,
+__global__ void __launch_bounds__(512) rnorm_undo_lds_kernel(const float* __restrict__ dout, const float* __restrict__ in, float* __restrict__ out, size_t locs, int C,
                                       int sizeF, float addScale, float powScale, bool blocked, bool vec, unsigned tiles, bool xcd) {
   extern __shared__ __attribute__((aligned(16))) float rn_smem[];
   float* xs = rn_smem;            // [C][LT] inputs

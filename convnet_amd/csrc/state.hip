@@ -171,6 +171,7 @@ int convnet_hip_init(int device_id) {
 }
 
 void convnet_hip_shutdown(void) {
+  flush_pending();   // (a parked call uses the arenas freed below)
   hipDeviceSynchronize();
   for (auto& per_stream : g_arena) {
     for (auto& kv : per_stream)
@@ -189,7 +190,10 @@ void convnet_hip_set_deferred_epilogues(int on) {
 }
 int convnet_hip_get_deferred_epilogues(void) { return defer_on() ? 1 : 0; }
 long convnet_hip_deferred_absorbed(void) { return chip::g_absorbed; }
-void* convnet_hip_get_stream(void) { return (void*)g_stream; }
+void* convnet_hip_get_stream(void) {
+  flush_pending();   // a host that enqueues its own work on the stream must find the parked call in front of it
+  return (void*)g_stream;
+}
 
 int convnet_hip_reserve_workspace(size_t bytes) {
   workspace(bytes);
@@ -199,9 +203,15 @@ int convnet_hip_reserve_workspace(size_t bytes) {
 const char* convnet_hip_version(void) { return "convnet_hip 0.2 (gfx950; fp32 products via bf16-split or fp32 MFMA)"; }
 void convnet_hip_set_matrix_path(int path) { chip::g_matrix_path = path != 0 ? 1 : 0; }
 int convnet_hip_get_matrix_path(void) { return chip::matrix_path(); }
-const char* get_last_cuda_error(void) { return g_last_error.c_str(); }
+const char* get_last_cuda_error(void) {
+  flush_pending();
+  return g_last_error.c_str();
+}
 
-int cuda_set_device(int deviceId) { return hipSetDevice(deviceId) == hipSuccess ? 0 : CUDA_ERROR; }
+int cuda_set_device(int deviceId) {
+  flush_pending();   // a parked call holds pointers of the device that was current when it was made
+  return hipSetDevice(deviceId) == hipSuccess ? 0 : CUDA_ERROR;
+}
 
 void cuda_sync_threads(void) { CHIP_CHECK(hipStreamSynchronize(stream())); }
 
@@ -227,7 +237,10 @@ int cublas_shutdown(void) {
   return 0;
 }
 
-void convnet_hip_last_kernel_info(ConvnetHipKernelInfo* out) { *out = g_info; }
+void convnet_hip_last_kernel_info(ConvnetHipKernelInfo* out) {
+  flush_pending();   // "the last conv / dot call" includes a parked one
+  *out = g_info;
+}
 
 void convnet_hip_profile_enable(int on) { g_prof_on = on != 0; }
 

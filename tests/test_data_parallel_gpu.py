@@ -429,9 +429,11 @@ def test_bench_configuration_two_streams_and_exchange_are_bit_identical_to_the_s
 def test_bench_launches_two_ranks_and_prints_the_scale_line(tmp_path):
     """`python bench.py --gpus 2` as the driver's SCALE run starts it, on this 1-GPU box: --share-device puts both ranks on GPU 0 and
     swaps RCCL for gloo (RCCL refuses two ranks on one device), everything else is the N-rank path — the self-launch through
-    torch.distributed.run, the weak run with the overlapped exchange, the strong leg (global 256 = 128 per GPU, with and without the
-    exchange), the ONE JSON line.  Asserts what a SCALE record needs: the line parses, `value` is the weak whole-job rate (global 512),
-    `strong` / `config4_value` are config 4, and the replicas hold bit-identical parameters after the timed steps."""
+    torch.distributed.run, the headline run with the overlapped exchange, the legs beside it, the ONE JSON line.  Asserts what a SCALE
+    record needs: the top-level `value` / `config` are BASELINE's configuration 4 — a GLOBAL batch of 256 split over
+    the ranks, 128 per GPU here — the weak run (256 per GPU, global 512) is nested as `weak`, `exchange_ms_exposed` = the step with the
+    exchange minus the same step without it, `rccl_ranks` counts RCCL ranks only (0 here: gloo carried the exchange), and the replicas
+    hold bit-identical parameters after the timed steps."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
@@ -443,12 +445,13 @@ def test_bench_launches_two_ranks_and_prints_the_scale_line(tmp_path):
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["warmup"] == 1
-    assert d["config"]["batch_per_gpu"] == 256 and d["config"]["global_batch"] == 512 and d["config"]["parallelism"].startswith("dp2")
-    assert abs(d["value"] - 512 * 3 / (d["ms_per_step"] * 3e-3)) < 0.01 * d["value"]      # whole-job images/s over all ranks
-    s = d["strong"]
-    assert s["scaling"] == "strong" and s["global_batch"] == 256 and s["batch_per_gpu"] == 128 and s["n_gpus"] == 2 and s["rccl_ranks"] == 2
-    assert d["config4_value"] == s["value"] and s["value"] > 0 and s["compute_only_ms_per_step"] > 0
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3 and d["warmup"] == 1
+    assert d["config"]["batch_per_gpu"] == 128 and d["config"]["global_batch"] == 256 and d["config"]["parallelism"].startswith("dp2")
+    assert abs(d["value"] - 256 * 3 / (d["ms_per_step"] * 3e-3)) < 0.01 * d["value"]      # whole-job images/s over all ranks
+    assert d["config4_value"] == d["value"] and d["compute_only_ms_per_step"] > 0
+    assert abs(d["exchange_ms_exposed"] - (d["ms_per_step"] - d["compute_only_ms_per_step"])) < 2e-3
+    w = d["weak"]
+    assert w["scaling"] == "weak" and w["global_batch"] == 512 and w["batch_per_gpu"] == 256 and w["n_gpus"] == 2 and w["value"] > 0
     assert d["replicas_identical"] is True
-    assert d["rccl_ranks"] == 2 and "share_device" in d
+    assert d["rccl_ranks"] == 0 and w["rccl_ranks"] == 0 and "share_device" in d      # gloo, not RCCL, carried the exchange
     assert d["roofline"] and d["roofline"]["frac"] <= 1.0
