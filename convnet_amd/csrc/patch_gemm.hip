@@ -1737,6 +1737,30 @@ inline WidePlan wide_plan(const GGParams& p, size_t dst_elems, int slots) {
   const int nsc = CB * TYn * p.ng, kchunks = CB * p.TYX;
   const double block_rate = 230e12 / slots;
   const double fl = 2.0 * rows * (double)(kWideP * 64) * (double)p.K;
+  auto finish = [&](int sp) {
+    const int cps = divup(nsc, sp);
+    return divup(nsc, cps);
+  };
+  // Round 6 (profiles/r06_batch_policy.txt): ONE round first.  Blocks that all run at once finish together whatever share of the chip
+  // they fill — and on a power-limited part a half-empty chip clocks its busy CUs higher (conv4 at 128 images, 129 tiles: 1.35 us per
+  // chunk against 2.05 with every CU busy).  Measured against ggp_kernel: gpw_kernel wins at 0.77 fill in three K-ranges (conv3 / conv4 /
+  // conv5 at 64 images: 66 tiles, 7-12 %) and at 0.67 in two (conv3 dgrad at 128 images: 219 vs 251 us), loses at 0.66 in ONE K-range
+  // (conv3 dgrad at 256 images: 170 whole-K tiles, 401 vs 343 + 23 us with ggp_kernel's tail split) and at 0.50 (129 tiles at 128 images).
+  if (tiles <= slots) {
+    int best_sp = 1;
+    double best_t = 1e30;
+    for (int sp = 1; sp <= 16 && tiles * sp <= slots && (sp == 1 || (dst_elems > 0 && kchunks / sp >= 8 && nsc / sp >= 1)); ++sp) {
+      double t = (fl / sp) / block_rate;
+      if (sp > 1) t += sizeof(float) * (double)dst_elems * (2.0 * sp + 1) / 4.0e12 + 4e-6;
+      if (t < best_t * 0.97) {
+        best_t = t;
+        best_sp = sp;
+      }
+    }
+    const int sp = finish(best_sp);
+    const double fill = (double)tiles * sp / slots;
+    if (fill >= (wide_is_var(p) ? 0.85 : sp > 1 ? 0.60 : 0.75)) return {sp, true};
+  }
   int splits = 1;
   if (dst_elems > 0 && kchunks >= 16) {
     double best_t = 1e30;
@@ -1750,8 +1774,7 @@ inline WidePlan wide_plan(const GGParams& p, size_t dst_elems, int slots) {
       }
     }
   }
-  const int cps = divup(nsc, splits);
-  splits = divup(nsc, cps);
+  splits = finish(splits);
   const long long blocks = (long long)tiles * splits;
   const long long rounds = (blocks + slots - 1) / slots;
   const bool fill = (double)blocks >= 0.85 * (double)(rounds * slots) || (splits == 1 && rounds >= 4);   // (many rounds: the tail split evens the last)

@@ -25,6 +25,7 @@ pytestmark = pytest.mark.gpu
 import oracle  # noqa: E402
 from oracle import Geom  # noqa: E402
 from golden_cases import rel_err  # noqa: E402
+from fp64_ref import ref_up as _ref_up, ref_down as _ref_down, ref_outp as _ref_outp  # noqa: E402
 
 TOL = 1e-4
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -194,40 +195,6 @@ def _alex_geoms(N=256):
 def _dot64(a, b, chunk=1 << 24):
     a, b = a.reshape(-1), b.reshape(-1)
     return float(sum(np.dot(a[i:i + chunk].astype(np.float64), b[i:i + chunk].astype(np.float64)) for i in range(0, a.size, chunk)))
-
-
-def _ref_up(g, x, w, f, oy, ox, n):
-    acc = 0.0
-    for ky in range(g.Ky):
-        for kx in range(g.Kx):
-            iy, ix = oy * g.sy + ky - g.pady, ox * g.sx + kx - g.padx
-            if 0 <= iy < g.H and 0 <= ix < g.W:
-                acc += float(np.dot(x[:, iy, ix, n].astype(np.float64), w[:, ky, kx, f].astype(np.float64)))
-    return acc
-
-
-def _ref_down(g, dy, w, c, iy, ix, n):
-    acc = 0.0
-    for ky in range(g.Ky):
-        for kx in range(g.Kx):
-            ty, tx = iy + g.pady - ky, ix + g.padx - kx
-            if ty % g.sy or tx % g.sx:
-                continue
-            oy, ox = ty // g.sy, tx // g.sx
-            if 0 <= oy < g.My and 0 <= ox < g.Mx:
-                acc += float(np.dot(dy[:, oy, ox, n].astype(np.float64), w[c, ky, kx, :].astype(np.float64)))
-    return acc
-
-
-def _ref_outp(g, x, dy, c, ky, kx, f):
-    # all output locations whose tap (ky,kx) falls inside the image
-    oy = np.arange(g.My)
-    ox = np.arange(g.Mx)
-    iy, ix = oy * g.sy + ky - g.pady, ox * g.sx + kx - g.padx
-    my, mx = (iy >= 0) & (iy < g.H), (ix >= 0) & (ix < g.W)
-    xs = x[c][np.ix_(iy[my], ix[mx])].astype(np.float64)        # (oy, ox, N)
-    ds = dy[f][np.ix_(oy[my], ox[mx])].astype(np.float64)
-    return float((xs * ds).sum())
 
 
 @pytest.mark.parametrize("layer", ["conv1", "conv2", "conv3", "conv4", "conv5"])

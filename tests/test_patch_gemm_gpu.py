@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 import oracle  # noqa: E402
 from oracle import Geom  # noqa: E402
 from golden_cases import rel_err  # noqa: E402
+from fp64_ref import ref_up  # noqa: E402
 
 TOL = 1e-4
 DEFAULT_MODE = 3   # include/convnet_hip.h: gpw_kernel where its launch policy takes the launch, ggp_kernel elsewhere
@@ -199,15 +200,18 @@ def test_wide_agrees_with_gpp_raw(hip):
 
 
 def test_wide_launch_policy(hip):
-    """Mode 3, the default: gpw_kernel takes the launches that fill their rounds on the chip (conv4 at 256 images: 255 tiles on 256
-    CUs; conv5 fprop: 122 tiles in two K-ranges), leaves the others to ggp_kernel (conv3 dgrad: 170 tiles, three K-ranges over two
-    rounds measured slower than ggp_kernel's tail split; small problems) — and both give the oracle's result."""
+    """Mode 3, the default: gpw_kernel takes the launches that run in ONE round filling the chip (conv4 at 256 images: 255 tiles on 256
+    CUs; conv5 fprop: 122 tiles in two K-ranges) and — since round 6 — the K-split ones from 0.6 fill (conv3 at 64 images: 66 tiles in
+    three K-ranges, measured 7-12 % ahead), leaves the others to ggp_kernel (conv3 dgrad at 256 images: 170 whole-K tiles measured 401 us
+    against 366 with ggp_kernel's tail split; conv4 at 128 images: 129 tiles = half the chip; small problems) — and both give the oracle's result."""
     from convnet_amd import _lib
     assert _lib.lib.convnet_hip_get_patch_mode() == DEFAULT_MODE
     rng = np.random.default_rng(34)
     takes = [
         (Geom(N=256, C=384, H=13, W=13, F=256, Ky=3, Kx=3), "fprop", True),                   # conv5 fprop: 122 tiles x 2 K-ranges
         (Geom(N=256, C=256, H=13, W=13, F=384, Ky=3, Kx=3, pady=1, padx=1), "dgrad", False),  # conv3 dgrad: 170 tiles
+        (Geom(N=64, C=256, H=13, W=13, F=384, Ky=3, Kx=3, pady=1, padx=1), "fprop", True),    # conv3 at 64 images: 66 tiles x 3 K-ranges
+        (Geom(N=128, C=384, H=13, W=13, F=384, Ky=3, Kx=3, pady=1, padx=1), "fprop", False),  # conv4 at 128 images: 129 tiles
         (Geom(N=64, C=32, H=9, W=9, F=96, Ky=3, Kx=3, pady=1, padx=1), "fprop", False),       # 11 tiles
     ]
     for g, which, wide_expected in takes:
@@ -229,8 +233,10 @@ def test_wide_launch_policy(hip):
 def test_wide_tail_split_on_hardware(hip):
     """More tiles than CUs and a partial last round: gpw_kernel cuts only the last round's tiles in K and gpw_tail_fix_kernel sums
     their partial tiles (VGG-size layers take this path; the emulation covered it, tests/test_emulated_kernels.py).  1 058 tiles on 256
-    CUs: four whole rounds and 34 tail tiles; the reference is the default gather kernel on the same data (oracle-checked itself; the
-    layer is 80 GFLOP)."""
+    CUs: four whole rounds and 34 tail tiles.  The layer is 80 GFLOP — beyond a whole-tensor pass of the CPU oracle — so the check is a
+    float64 evaluation of the reference's definition (cudamat_conv_gemm.cu:545-640) at sampled outputs: the image corners and borders,
+    the LAST tiles of the launch (the K-cut ones: the highest filter block's last pixels) and random ones; the default gather kernel
+    runs beside it on the same data only to show that the two K partitions agree to rounding."""
     from convnet_amd import _lib
     g = Geom(N=64, C=64, H=92, W=92, F=128, Ky=3, Kx=3, pady=1, padx=1)
     rng = np.random.default_rng(35)
@@ -246,6 +252,14 @@ def test_wide_tail_split_on_hardware(hip):
             assert last_kernel() == "gpw_kernel(fprop)" and any(n.startswith("gpw_kernel") for n in names), (last_kernel(), names)
             assert any(n == "gg_tail_fix_kernel" for n in names), names
     _lib.lib.convnet_hip_set_patch_mode(DEFAULT_MODE)
+    y = outs[1]
+    scale = float(np.abs(y).mean())
+    picks = [(f, oy, ox, n) for f in (0, 127) for (oy, ox) in ((0, 0), (0, 91), (91, 0), (91, 91), (90, 84), (91, 88), (45, 46)) for n in (0, 63)]
+    picks += [(int(rng.integers(g.F)), int(rng.integers(80, g.My)), int(rng.integers(g.Mx)), int(rng.integers(g.N))) for _ in range(32)]   # the last rows: the tail tiles
+    picks += [(int(rng.integers(g.F)), int(rng.integers(g.My)), int(rng.integers(g.Mx)), int(rng.integers(g.N))) for _ in range(32)]
+    for (f, oy, ox, n) in picks:
+        want = ref_up(g, x, w, f, oy, ox, n)
+        assert abs(want - y[f, oy, ox, n]) < TOL * scale, ("fprop", f, oy, ox, n, want, y[f, oy, ox, n])
     assert rel_err(outs[1], outs[0]) < 1e-5
 
 

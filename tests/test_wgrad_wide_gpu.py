@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 import oracle  # noqa: E402
 from oracle import Geom  # noqa: E402
 from golden_cases import rel_err  # noqa: E402
+from fp64_ref import ref_outp  # noqa: E402
 
 TOL = 1e-4
 
@@ -123,8 +124,10 @@ def test_wide_agrees_with_wg_kernel(hip):
 def test_wide_single_block_epilogue_on_hardware(hip, wide):
     """>= 256 tiles: one block per tile, no slabs — scaleTargets / scaleOutput and the bias row in the kernel's OWN write-out (the AlexNet
     layers never get there: their 10-28 tiles are cut in K; the emulation covered this path, tests/test_emulated_kernels.py).  A layer
-    that size is beyond the CPU oracle's reach, so the reference here is wg_kernel on the same data (itself oracle-checked): same operand
-    splits and products, another partition of the reduction."""
+    that size is beyond a whole-tensor pass of the CPU oracle, so the check is a float64 evaluation of the reference's definition
+    (cudamat_conv_gemm.cu:827-960) at sampled weights — every k-tile and filter-tile corner, the spare bias row's neighbours and random
+    ones — plus the whole bias gradient in float64; wg_kernel runs beside it on the same data only to show that the two partitions of
+    the reduction agree to rounding."""
     from convnet_amd import _lib
     from hip_adapter import conv_outp_bias
     g = Geom(N=32, C=500, H=8, W=8, F=4096, Ky=3, Kx=3, pady=1, padx=1)   # K = 4500: 18 k-tiles (a spare row for the bias) x 16 filter tiles = 288
@@ -143,6 +146,13 @@ def test_wide_single_block_epilogue_on_hardware(hip, wide):
             assert not any("reduce" in n for n in names), names   # one block per tile: nothing to reduce
         outs.append((dw, db))
     _lib.lib.convnet_hip_set_wgrad_tile(1)
-    assert rel_err(outs[1][0], outs[0][0]) < 1e-5 and rel_err(outs[1][1], outs[0][1]) < 1e-5
+    dw, db = outs[1]
+    scale = float(np.abs(dw - dw0).mean())
+    picks = [(c, ky, kx, f) for c in (0, 28, 56, 499) for (ky, kx) in ((0, 0), (1, 1), (2, 2)) for f in (0, 255, 256, 4095)]   # tile corners: k = 9c + 3ky + kx
+    picks += [(int(rng.integers(g.C)), int(rng.integers(3)), int(rng.integers(3)), int(rng.integers(g.F))) for _ in range(48)]
+    for (c, ky, kx, f) in picks:
+        want = float(dw0[c, ky, kx, f]) + 0.5 * ref_outp(g, x, dy, c, ky, kx, f)
+        assert abs(want - dw[c, ky, kx, f]) < TOL * scale, ("wgrad", c, ky, kx, f, want, dw[c, ky, kx, f])
     ref_db = db0 + 0.5 * dy.reshape(g.F, -1).astype(np.float64).sum(axis=1)
-    assert rel_err(outs[1][1], ref_db.astype(np.float32)) < TOL
+    assert rel_err(db, ref_db.astype(np.float32)) < TOL
+    assert rel_err(dw, outs[0][0]) < 1e-5 and rel_err(db, outs[0][1]) < 1e-5
