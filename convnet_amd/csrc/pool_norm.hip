@@ -618,6 +618,234 @@ __global__ void __launch_bounds__(512) rnorm_undo_lds_kernel(const float* __rest
   }
 }
 
+// ---- the AlexNet form of the two kernels (round 6): window and segment known at compile time, pipelined ----------------------------------
+// AlexNet's windows are a quarter of the channels (frac_of_filters_response_norm 0.25: 24 of 96, 64 of 256).  Measured on rnorm1's undo,
+// the LDS-tiled kernels above are ISSUE-bound, not latency-bound: ~130 instructions per element (window bounds, two variable-length
+// slide loops and their LDS addresses per channel, a 24- or 64-term first window per 6 or 8 channels, the scalar tail paths of ldv);
+// giving that kernel loads in flight throughout (a persistent block that fetches its next tile into registers) moved it by 10 % only.
+// Here, for an even window SZ with SZ/2 a multiple of the CG channels a lane owns:
+//   * the channel loop is unrolled and the slides are two LDS reads at compile-time offsets, in the oracle's order (subtract the channel
+//     that leaves, add the one that enters, cpumat_conv.cc:476-490).  Rows of zeros below channel 0 and above channel C - 1 stand in for
+//     the clipped window ends (x - 0*0 and x + 0*0 are exact): no bounds anywhere;
+//   * a lane's FIRST window is the sum of SZ / CG segment sums — every lane squares and adds its own CG channels once and leaves the sum
+//     in LDS — instead of SZ terms per lane (a different association of the same terms; the slides start from it);
+//   * the block is persistent over a strided run of its XCD's tiles and fetches the NEXT tile into registers right after the current one
+//     has been put into LDS (loads in flight during the whole compute and write-out), from per-lane pointers set up once;
+//   * results leave through LDS as 16-byte vectors: a quarter of the store instructions;
+//   * when C is not a multiple of CG the last lanes' spare channels read the zero rows, compute zeros and write them back into zero rows
+//     (the arrays are CG rows longer than C); only rows < C are copied out.
+// Launch: blockDim.x = ceil(C / CG) * LT, gridDim.x = 8 * (blocks per XCD); 16-byte rows (vec), !blocked only.
+template <int NV>
+struct RnLanes {          // this lane's 16-byte pieces of a [C][LT] tile: offset in the tensor (channel * locs + 4 * quad), or -1
+  long long off[NV];
+  int last_q[NV];         // quad index inside the tile (for the ragged last tile)
+};
+template <int NV>
+__device__ __forceinline__ RnLanes<NV> rn_lanes(size_t locs, int C, int L4) {
+  RnLanes<NV> r;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int idx = threadIdx.x + k * blockDim.x;
+    const int c = idx / L4, q = idx - c * L4;
+    r.off[k] = c < C ? (long long)((size_t)c * locs + 4 * q) : -1;
+    r.last_q[k] = 4 * q;
+  }
+  return r;
+}
+template <int NV>
+__device__ __forceinline__ void rn_fetch(const float* __restrict__ g, const RnLanes<NV>& ln, f32x4 (&r)[NV], size_t locs, size_t l0) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ln.off[k] >= 0 && l0 + ln.last_q[k] < locs) v = *reinterpret_cast<const f32x4*>(g + ln.off[k] + l0);
+    r[k] = v;
+  }
+}
+template <int NV>
+__device__ __forceinline__ void rn_put(float* __restrict__ s, const f32x4 (&r)[NV], int n4) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int idx = threadIdx.x + k * blockDim.x;   // element 4 * idx of the [C][LT] array
+    if (idx < n4) *reinterpret_cast<f32x4*>(s + 4 * idx) = r[k];
+  }
+}
+template <int NV>
+__device__ __forceinline__ void rn_copy_out(const float* __restrict__ s, float* __restrict__ out, const RnLanes<NV>& ln, size_t locs, size_t l0) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int idx = threadIdx.x + k * blockDim.x;
+    if (ln.off[k] >= 0 && l0 + ln.last_q[k] < locs) *reinterpret_cast<f32x4*>(out + ln.off[k] + l0) = *reinterpret_cast<const f32x4*>(s + 4 * idx);
+  }
+}
+struct RnRun {
+  unsigned t, hi, step;
+};
+__device__ __forceinline__ RnRun rn_run(unsigned tiles) {
+  const unsigned per = (tiles + 7) >> 3, x = blockIdx.x & 7, lo = x * per;
+  return {lo + (blockIdx.x >> 3), min(tiles, lo + per), gridDim.x >> 3};
+}
+// zero rows below channel 0 / from channel C on (the spare channels of the last lanes and everything a window reaches above them)
+constexpr int rn_halo_lo(int SZ) { return SZ / 2; }
+constexpr int rn_halo_hi(int CG, int SZ) { return CG + SZ / 2 + 1; }
+// 2^x by the hardware instruction alone (v_exp_f32): exp2f() wraps it in a range fix for results below 2^-126, which a power
+// (1 + a*S)^(-b) only reaches for sums of squares near the top of the fp32 range
+__device__ __forceinline__ float rn_exp2(float x) {
+#ifdef CONVNET_EMU
+  return exp2f(x);
+#else
+  return __builtin_amdgcn_exp2f(x);
+#endif
+}
+
+// first window of a lane = 2 * NQ sub-segment sums on either side of its first channel; a lane owns NSUB sub-segments of SS channels
+template <int CG, int SZ>
+struct RnSeg {
+  static constexpr int H = SZ / 2, SS = CG < H ? CG : H, NSUB = CG / SS, NQ = H / SS;
+  static_assert(SZ % 2 == 0 && CG % SS == 0 && H % SS == 0, "the first window is a whole number of sub-segments on either side");
+};
+
+template <int LT, int CG, int SZ>
+__global__ void __launch_bounds__(512) rnorm_fwd_fast_kernel(const float* __restrict__ in, float* __restrict__ out, size_t locs, int C, float addScale,
+                                                             float powScale, bool relu, unsigned tiles) {
+  using Seg = RnSeg<CG, SZ>;
+  constexpr int NV = (CG + 3) / 4, L4 = LT / 4, HLO = rn_halo_lo(SZ), HHI = rn_halo_hi(CG, SZ), H = Seg::H, SS = Seg::SS, NSUB = Seg::NSUB, NQ = Seg::NQ;
+  extern __shared__ __attribute__((aligned(16))) float rn_smem[];
+  const int G = blockDim.x / LT;
+  float* xs = rn_smem + HLO * LT;                              // rows -HLO .. C + HHI - 1
+  float* ys = rn_smem + (HLO + C + HHI) * LT;                  // rows 0 .. C + CG - 1
+  float* sx = ys + (C + CG) * LT + NQ * LT;                    // sub-segment sums of x^2: rows -NQ .. G * NSUB + NQ - 1
+  RnRun run = rn_run(tiles);
+  if (run.t >= run.hi) return;
+  for (int i = threadIdx.x; i < HLO * LT; i += blockDim.x) xs[i - HLO * LT] = 0.f;
+  for (int i = threadIdx.x; i < HHI * LT; i += blockDim.x) xs[C * LT + i] = 0.f;
+  for (int i = threadIdx.x; i < NQ * LT; i += blockDim.x) sx[i - NQ * LT] = sx[G * NSUB * LT + i] = 0.f;
+  const int l = threadIdx.x % LT, g = threadIdx.x / LT, j0 = g * CG;
+  const RnLanes<NV> ln = rn_lanes<NV>(locs, C, L4);
+  f32x4 rx[NV];
+  rn_fetch<NV>(in, ln, rx, locs, (size_t)run.t * LT);
+  for (; run.t < run.hi; run.t += run.step) {
+    const size_t l0 = (size_t)run.t * LT;
+    rn_put<NV>(xs, rx, C * L4);
+    __syncthreads();
+    if (run.t + run.step < run.hi) rn_fetch<NV>(in, ln, rx, locs, (size_t)(run.t + run.step) * LT);
+    float xo[CG];
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {
+      float seg = 0.f;
+#pragma unroll
+      for (int c = u * SS; c < (u + 1) * SS; ++c) {
+        xo[c] = xs[(j0 + c) * LT + l];
+        seg += xo[c] * xo[c];
+      }
+      sx[(g * NSUB + u) * LT + l] = seg;
+    }
+    __syncthreads();
+    float sum = 0.f;   // window of channel j0: [j0 - H, j0 + H)
+#pragma unroll
+    for (int q = -NQ; q < NQ; ++q) sum += sx[(g * NSUB + q) * LT + l];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+      if (c > 0) {
+        const float a = xs[(j0 + c - 1 - H) * LT + l], b = xs[(j0 + c - 1 + H) * LT + l];
+        sum -= a * a;
+        sum += b * b;
+      }
+      // u^(-b) = exp2(-b * log2(u)), u >= 1 (see rnorm_fwd_lds_kernel)
+      const float y = xo[c] * rn_exp2(-powScale * __log2f(1.f + addScale * sum));
+      ys[(j0 + c) * LT + l] = relu ? fmaxf(y, 0.f) : y;
+    }
+    __syncthreads();
+    rn_copy_out<NV>(ys, out, ln, locs, l0);
+    // (the next put writes xs, which nobody reads any more; the next tile's sx / ys writes come behind the next barriers)
+  }
+}
+
+template <int LT, int CG, int SZ>
+__global__ void __launch_bounds__(512) rnorm_undo_fast_kernel(const float* __restrict__ dout, const float* __restrict__ in, float* __restrict__ out,
+                                                              size_t locs, int C, float addScale, float powScale, unsigned tiles) {
+  using Seg = RnSeg<CG, SZ>;
+  constexpr int NV = (CG + 3) / 4, L4 = LT / 4, HLO = rn_halo_lo(SZ), HHI = rn_halo_hi(CG, SZ), H = Seg::H, SS = Seg::SS, NSUB = Seg::NSUB, NQ = Seg::NQ;
+  extern __shared__ __attribute__((aligned(16))) float rn_smem[];
+  const int G = blockDim.x / LT, R = HLO + C + HHI;
+  float* xs = rn_smem + HLO * LT;                 // rows -HLO .. C + HHI - 1: inputs, then the results
+  float* ps_ = rn_smem + (R + HLO) * LT;          // rows -HLO .. C + HHI - 1: out-grads, then (element by element, each by the lane that owns it)
+                                                  // prod = dout * in * den,  den = (1 + a*S)^(-b-1)
+  float* sx = rn_smem + 2 * R * LT + NQ * LT;     // sub-segment sums of x^2: rows -NQ .. G * NSUB + NQ - 1
+  float* sp = sx + (G * NSUB + 2 * NQ) * LT;      // ... of prod
+  RnRun run = rn_run(tiles);
+  if (run.t >= run.hi) return;
+  for (int i = threadIdx.x; i < HLO * LT; i += blockDim.x) xs[i - HLO * LT] = ps_[i - HLO * LT] = 0.f;
+  for (int i = threadIdx.x; i < HHI * LT; i += blockDim.x) xs[C * LT + i] = ps_[C * LT + i] = 0.f;
+  for (int i = threadIdx.x; i < NQ * LT; i += blockDim.x) sx[i - NQ * LT] = sx[G * NSUB * LT + i] = sp[i - NQ * LT] = sp[G * NSUB * LT + i] = 0.f;
+  const int l = threadIdx.x % LT, g = threadIdx.x / LT, j0 = g * CG;
+  const float k2 = 2 * addScale * powScale;
+  const RnLanes<NV> ln = rn_lanes<NV>(locs, C, L4);
+  f32x4 rx[NV], rd[NV];
+  rn_fetch<NV>(in, ln, rx, locs, (size_t)run.t * LT);
+  rn_fetch<NV>(dout, ln, rd, locs, (size_t)run.t * LT);
+  for (; run.t < run.hi; run.t += run.step) {
+    const size_t l0 = (size_t)run.t * LT;
+    rn_put<NV>(xs, rx, C * L4);
+    rn_put<NV>(ps_, rd, C * L4);
+    __syncthreads();
+    if (run.t + run.step < run.hi) {
+      rn_fetch<NV>(in, ln, rx, locs, (size_t)(run.t + run.step) * LT);
+      rn_fetch<NV>(dout, ln, rd, locs, (size_t)(run.t + run.step) * LT);
+    }
+    float xo[CG], sc[CG];
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {
+      float seg = 0.f;
+#pragma unroll
+      for (int c = u * SS; c < (u + 1) * SS; ++c) {
+        xo[c] = xs[(j0 + c) * LT + l];
+        seg += xo[c] * xo[c];
+      }
+      sx[(g * NSUB + u) * LT + l] = seg;
+    }
+    __syncthreads();
+    {
+      float sum = 0.f, pseg = 0.f;   // forward window of channel j0: [j0 - H, j0 + H)
+#pragma unroll
+      for (int q = -NQ; q < NQ; ++q) sum += sx[(g * NSUB + q) * LT + l];
+#pragma unroll
+      for (int c = 0; c < CG; ++c) {
+        if (c > 0) {
+          const float a = xs[(j0 + c - 1 - H) * LT + l], b = xs[(j0 + c - 1 + H) * LT + l];
+          sum -= a * a;
+          sum += b * b;
+        }
+        const float lg = __log2f(1.f + addScale * sum);
+        const float den = rn_exp2((-powScale - 1.f) * lg);        // (1 + a*S)^(-b-1)
+        const float d = ps_[(j0 + c) * LT + l];                   // (the spare channels of the last lanes: a zero row)
+        const float pr = d * xo[c] * den;
+        ps_[(j0 + c) * LT + l] = pr;
+        pseg += pr;
+        sc[c] = d * rn_exp2(-powScale * lg);                      // d * (1 + a*S)^(-b)
+        if ((c + 1) % SS == 0) {
+          sp[(g * NSUB + c / SS) * LT + l] = pseg;
+          pseg = 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    {
+      float sum = 0.f;   // [j0 - H, j0 + H), then one slide to the backward window of channel j0: [j0 - H + 1, j0 + H + 1)
+#pragma unroll
+      for (int q = -NQ; q < NQ; ++q) sum += sp[(g * NSUB + q) * LT + l];
+#pragma unroll
+      for (int c = 0; c < CG; ++c) {
+        sum -= ps_[(j0 + c - H) * LT + l];
+        sum += ps_[(j0 + c + H) * LT + l];
+        xs[(j0 + c) * LT + l] = sc[c] - k2 * xo[c] * sum;   // (every lane has read its inputs: the rows now carry the result)
+      }
+    }
+    __syncthreads();
+    rn_copy_out<NV>(xs, out, ln, locs, l0);
+    __syncthreads();   // ... before the next tile's inputs overwrite them
+  }
+}
+
 namespace {
 
 inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -641,6 +869,110 @@ inline int grid_for(size_t items) {
   size_t b = (items + 255) / 256;
   if (b > 4096) b = 4096;
   return b ? (int)b : 1;
+}
+
+// Launch geometry of the persistent response-norm kernels: blocks per XCD = twice what its 32 CUs hold at once (the runtime's occupancy
+// figure for this kernel, block size and LDS: registers, LDS and wave slots), never more than the XCD has tiles.
+inline unsigned rn_pipe_grid(const void* kernel, unsigned tiles, size_t smem, int threads) {
+  struct Key { const void* k; size_t smem; int threads; int n; };
+  static thread_local Key cache[8] = {};
+  int n = 0;
+  for (const Key& e : cache)
+    if (e.k == kernel && e.smem == smem && e.threads == threads) n = e.n;
+  if (!n) {
+    if (smem > 64 * 1024) CHIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    CHIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, smem));
+    if (n < 1) n = 1;
+    static thread_local int next = 0;
+    cache[next++ & 7] = {kernel, smem, threads, n};
+  }
+  n *= 2;   // twice what is resident: the second half starts as the first blocks finish their (shorter) runs — measured 2-4 % ahead of exactly resident
+  if (const int f = CHIP_DIAG_KNOB("CONVNET_RNORM_PIPE_BPC", 0)) n = f;
+  const unsigned per = (tiles + 7) / 8;
+  return 8 * std::min(per, 32u * (unsigned)n);
+}
+
+// Shape of the fast kernels: window 24 (AlexNet's rnorm1: a quarter of 96 channels) with 6 / 12 / 24 channels per lane, window 64
+// (rnorm2: a quarter of 256) with 8, LT locations per tile, ceil(C / CG) * LT threads.  false: none (the LDS-tiled kernels take the call).
+struct RnFast {
+  int CG, LT, threads, SZ;
+};
+inline bool rn_fast_shape(int C, int sizeF, bool blocked, bool vec, bool undo, RnFast& f) {
+  if (!CHIP_KNOB("CONVNET_RNORM_FAST", 1) || blocked || !vec || C < sizeF) return false;
+  f.SZ = sizeF;
+  if (sizeF == 24) {
+    // rows of LT * 4 bytes: 128-byte rows run at 4.2 TB/s, 64-byte ones at 3.1 (rnorm1, profiles/r06_rnorm.txt)
+    f.CG = C <= 96 ? 12 : 6;
+    if (const int k = CHIP_DIAG_KNOB("CONVNET_RNORM_FAST_CG", 0)) f.CG = k;
+  } else if (sizeF == 64) {
+    f.CG = 8;
+  } else {
+    return false;
+  }
+  const int G = divup(C, f.CG);
+  f.LT = 128;
+  while (f.LT > 16 && G * f.LT > 512) f.LT /= 2;
+  if (f.LT == 128 && f.CG != 24) f.LT = 64;
+  f.threads = G * f.LT;
+  (void)undo;
+  return f.threads <= 512;
+}
+inline size_t rn_fast_rows(const RnFast& f, int C, bool undo) {
+  const int H = f.SZ / 2, SS = f.CG < H ? f.CG : H;
+  const int R = rn_halo_lo(f.SZ) + C + rn_halo_hi(f.CG, f.SZ), seg = divup(C, f.CG) * (f.CG / SS) + 2 * (H / SS);
+  return undo ? (size_t)2 * R + 2 * seg : (size_t)R + C + f.CG + seg;
+}
+
+bool rnorm_fwd_fast(const float* in, float* out, size_t locs, int C, int sizeF, float addScale, float powScale, bool blocked, bool vec, bool relu) {
+  RnFast f;
+  if (!rn_fast_shape(C, sizeF, blocked, vec, false, f)) return false;
+  const size_t smem = sizeof(float) * (size_t)f.LT * rn_fast_rows(f, C, false);
+  if (smem > 160 * 1024) return false;
+  const unsigned tiles = (unsigned)((locs + f.LT - 1) / f.LT);
+  const dim3 block(f.threads);
+#define RN_F(L, G, S)                                                                                                           \
+  do {                                                                                                                          \
+    const dim3 grid(rn_pipe_grid((const void*)rnorm_fwd_fast_kernel<L, G, S>, tiles, smem, f.threads));                          \
+    hipLaunchKernelGGL((rnorm_fwd_fast_kernel<L, G, S>), grid, block, smem, stream(), in, out, locs, C, addScale, powScale, relu, tiles); \
+  } while (0)
+  if (f.SZ == 24 && f.CG == 24 && f.LT == 128) RN_F(128, 24, 24);
+  else if (f.SZ == 24 && f.CG == 12 && f.LT == 64) RN_F(64, 12, 24);
+  else if (f.SZ == 24 && f.CG == 12 && f.LT == 32) RN_F(32, 12, 24);
+  else if (f.SZ == 24 && f.CG == 6 && f.LT == 64) RN_F(64, 6, 24);
+  else if (f.SZ == 24 && f.CG == 6 && f.LT == 32) RN_F(32, 6, 24);
+  else if (f.SZ == 24 && f.CG == 6 && f.LT == 16) RN_F(16, 6, 24);
+  else if (f.SZ == 64 && f.LT == 64) RN_F(64, 8, 64);
+  else if (f.SZ == 64 && f.LT == 32) RN_F(32, 8, 64);
+  else if (f.SZ == 64 && f.LT == 16) RN_F(16, 8, 64);
+  else return false;
+#undef RN_F
+  return true;
+}
+
+bool rnorm_undo_fast(const float* dout, const float* in, float* out, size_t locs, int C, int sizeF, float addScale, float powScale, bool blocked, bool vec) {
+  RnFast f;
+  if (!rn_fast_shape(C, sizeF, blocked, vec, true, f)) return false;
+  const size_t smem = sizeof(float) * (size_t)f.LT * rn_fast_rows(f, C, true);
+  if (smem > 160 * 1024) return false;
+  const unsigned tiles = (unsigned)((locs + f.LT - 1) / f.LT);
+  const dim3 block(f.threads);
+#define RN_U(L, G, S)                                                                                                           \
+  do {                                                                                                                          \
+    const dim3 grid(rn_pipe_grid((const void*)rnorm_undo_fast_kernel<L, G, S>, tiles, smem, f.threads));                         \
+    hipLaunchKernelGGL((rnorm_undo_fast_kernel<L, G, S>), grid, block, smem, stream(), dout, in, out, locs, C, addScale, powScale, tiles); \
+  } while (0)
+  if (f.SZ == 24 && f.CG == 24 && f.LT == 128) RN_U(128, 24, 24);
+  else if (f.SZ == 24 && f.CG == 12 && f.LT == 64) RN_U(64, 12, 24);
+  else if (f.SZ == 24 && f.CG == 12 && f.LT == 32) RN_U(32, 12, 24);
+  else if (f.SZ == 24 && f.CG == 6 && f.LT == 64) RN_U(64, 6, 24);
+  else if (f.SZ == 24 && f.CG == 6 && f.LT == 32) RN_U(32, 6, 24);
+  else if (f.SZ == 24 && f.CG == 6 && f.LT == 16) RN_U(16, 6, 24);
+  else if (f.SZ == 64 && f.LT == 64) RN_U(64, 8, 64);
+  else if (f.SZ == 64 && f.LT == 32) RN_U(32, 8, 64);
+  else if (f.SZ == 64 && f.LT == 16) RN_U(16, 8, 64);
+  else return false;
+#undef RN_U
+  return true;
 }
 
 PoolGeo pool_geo(const Shape4D* in, const Shape4D* out, const ConvDesc& d, const cudamat* mi, const cudamat* mo) {
@@ -793,6 +1125,7 @@ static void rnorm_fwd_impl(cudamat* images, cudamat* targets, int numFilters, in
     const int C = numFilters;
     int LT = C <= 192 ? 64 : (C <= 384 ? 32 : (C <= 768 ? 16 : 0));
     if (const int f = CHIP_DIAG_KNOB("CONVNET_RNORM_FWD_LT", 0)) LT = f;   // tuning knob (tools/pool_bench.py, -DCONVNET_DIAG builds)
+    if (rnorm_fwd_fast(images->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec, relu)) return;
     if (LT) {   // LDS-tiled, read-once/write-once
       const size_t smem = sizeof(float) * (size_t)C * LT;
       const bool xcd = !CHIP_DIAG_KNOB("CONVNET_RNORM_NO_XCD", 0);   // A/B switch for the XCD-contiguous tile order
@@ -843,10 +1176,11 @@ void ResponseNormCrossMapUndoGemm(cudamat* outGrads, cudamat* inputs, cudamat* t
     if (LT) {
       const bool vec = locs % 4 == 0 && a16(outGrads->data_device) && a16(inputs->data_device) && a16(targets->data_device);
       KernelTimer timer("rnorm_undo_kernels", "rnorm_undo", 0.0, 12.0 * total);
+      if (rnorm_undo_fast(outGrads->data_device, inputs->data_device, targets->data_device, locs, C, sizeF, addScale, powScale, blocked, vec)) return;
       const size_t smem = sizeof(float) * 3 * (size_t)C * LT;
       const bool xcd = !CHIP_DIAG_KNOB("CONVNET_RNORM_NO_XCD", 0);   // A/B switch for the XCD-contiguous tile order
       const unsigned tiles = (unsigned)((locs + LT - 1) / LT);
-      const dim3 grid(xcd ? (tiles + 7) / 8 * 8 : tiles), block(CHIP_DIAG_KNOB("CONVNET_RNORM_UNDO_THREADS", C > 128 ? 512 : 256));   // (rnorm2, C = 256: 75 -> 58 us with 8 instead of 16 channels per thread; C = 96: no difference)
+      const dim3 grid(xcd ? (tiles + 7) / 8 * 8 : tiles), block(CHIP_DIAG_KNOB("CONVNET_RNORM_UNDO_THREADS", 0) ? CHIP_DIAG_KNOB("CONVNET_RNORM_UNDO_THREADS", 0) : C > 128 ? 512 : 256);   // (rnorm2, C = 256: 75 -> 58 us with 8 instead of 16 channels per thread; C = 96: no difference)
       CHIP_REQUIRE(smem <= 160 * 1024);
 #define RN_UNDO(L)                                                                                                              \
   do {                                                                                                                          \

@@ -415,6 +415,10 @@ int main(int argc, char** argv) {
       pool_case(32, 8, 43, 3, 2);         // 21 x 21 outputs: the 2 x 2-block forward kernel with an odd last row and column
       rnorm_case(32, 96, 25, 5);          // rnorm1 type: 96 channels, window 5
       rnorm_case(16, 256, 9, 5);
+      rnorm_case(32, 96, 9, 24);          // rnorm1 itself: window 24 = the fast kernels' 6-channel segments
+      rnorm_case(16, 256, 4, 64);         // rnorm2 itself: window 64, 8-channel segments
+      rnorm_case(16, 100, 9, 24);         // 17 lane groups of 6 channels: two spare channels on the zero rows
+      rnorm_case(8, 70, 4, 64);           // 9 groups of 8, two spare channels; 32 locations = half a 64-location tile
       sgd_case(96, 147);
     }
   }

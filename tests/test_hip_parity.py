@@ -153,6 +153,14 @@ def test_max_pool_undo_routes_gradient_to_every_tie(hip):
     ((256, 3, 3, 8), 64, False),        # AlexNet rnorm2
     ((20, 2, 3, 5), 5, True),
     ((7, 2, 2, 3), 3, False),           # ragged location count
+    # the fast kernels of round 6 (pool_norm.hip: rnorm_fwd_fast_kernel / rnorm_undo_fast_kernel; windows 24 and 64, 16-byte rows)
+    ((96, 9, 7, 12), 24, False),        # 12 channels per lane, 64-location tiles: 756 locations = 11 whole tiles and a ragged one
+    ((96, 27, 27, 32), 24, False),      # 365 tiles over the persistent blocks of eight XCD ranges (several tiles per block: the register prefetch)
+    ((100, 5, 5, 16), 24, False),       # > 96 channels: 6 per lane, 17 lane groups, two spare channels on the zero rows
+    ((250, 3, 5, 8), 64, False),        # 8 per lane, 32 groups, six spare channels
+    ((64, 4, 4, 8), 64, False),         # the window spans every channel: all of it clipped at one end or the other
+    ((96, 5, 5, 15), 24, False),        # 375 locations: rows not 16-byte multiples -> the LDS-tiled kernels
+    ((96, 5, 5, 16), 24, True),         # blocked windows -> the LDS-tiled kernels
 ])
 def test_response_norm_vs_oracle(hip, shape, size_f, blocked):
     rng = np.random.default_rng(14)
