@@ -18,8 +18,11 @@ stream); `one_stream_ms_per_step` / `two_stream_ms_per_step` time the same K ste
 region, without kernel timers, so that what the second stream is worth on the box is on every line.
 
 Extra objects on the line:
-  roofline      dominant MFMA kernel: algorithmic flops / HIP-event time measured per launch inside
-                the timed region, against the peak of the matrix pipe the kernel EXECUTES on.  With the default
+  roofline      dominant MFMA kernel: algorithmic flops / HIP-event time per launch, against the peak of the matrix pipe the
+                kernel EXECUTES on.  The kernel's duration is taken with the launch alone on the chip — four fully timed one-stream
+                steps of this process right after the timed region (the clock that agrees with rocprofv3's serialised kernel trace,
+                `rocprof_avg_launch_ms`); the event spans of the same launches INSIDE the timed region, where the second stream's
+                weight-gradient kernel shares the chip, travel as `timed_region` with their own `frac`.  With the default
                 matrix path the fp32 products are formed on the bf16 pipe from exact three-way operand splits —
                 six v_mfma_f32_32x32x16_bf16 per 32x32x16 block (include/convnet_hip.h) — so one algorithmic flop
                 costs six bf16 flops and the ceiling in algorithmic units is 2500 / 6 = 416.7 TFLOP/s; `frac` =
@@ -378,9 +381,9 @@ def main():
     ap.add_argument("--weak", action="store_true",
                     help="with --gpus N > 1: --batch images on EVERY rank as the headline run (weak scaling).  Default for N > 1 is "
                          "BASELINE's configuration 4 — a GLOBAL batch of 256 split over the ranks — with the weak run nested as `weak`")
-    ap.add_argument("--timer-every", type=int, default=10,
+    ap.add_argument("--timer-every", type=int, default=20,
                     help="steps between kernel-timer (HIP event) sampled steps of the timed region (a sampled step costs ~0.6 ms of event packets: every "
-                         "10th step = 0.06 ms per step; the fully timed one-stream steps behind the region carry the per-family table)")
+                         "20th step = 0.03 ms per step; the fully timed one-stream steps behind the region carry the per-family table)")
     ap.add_argument("--no-kernel-timers", action="store_true", help="diagnostic: no per-launch HIP events (roofline fields empty)")
     ap.add_argument("--staged-input", action="store_true", help="GPU-resident 256x256 chunk + crop/flip/transpose staging per batch instead of pre-staged batches")
     ap.add_argument("--unfused", action="store_true", help="issue the reference's unfused Matrix-call sequence")
@@ -681,21 +684,38 @@ def main():
         roofline = None
         if mfma:
             # The dominant kernel is the MFMA family with the most time on the chip TO ITSELF: ranked by the one-stream steps (every
-            # launch alone) where they were run.  In the timed region the weight gradients share the chip with the backward pass's other
-            # GEMMs on the second stream, so a launch's event span includes its neighbour's: ranking by those stretched spans made
-            # whichever family co-runs most look dominant.  `achieved` / `frac` below remain what the contract asks for — this family's
-            # algorithmic flops over its event spans INSIDE the timed region; `one_stream` carries its undisturbed rate.
+            # launch alone) where they were run.  `achieved` / `frac` / `avg_launch_ms` are the kernel's DURATION: algorithmic flops over its
+            # HIP-event spans in the four fully timed one-stream steps of this process (the clock that agrees with rocprofv3's kernel trace,
+            # which serialises launches: `rocprof_avg_launch_ms`).  In the timed region itself the weight gradients run on a second stream
+            # beside the backward pass's other GEMMs, so a launch's event span THERE includes the time its blocks wait for CUs the other
+            # stream's kernel holds — a span, not a duration; it travels as `timed_region` (with its own `frac`) and is all there is when
+            # the one-stream steps were not run (--no-kernel-timers off but world > 1 etc.).
             alone_ms = {}
             for r in (prof_one_stream or []):
                 if r["flops"] > 0:
                     alone_ms[r["kernel"]] = alone_ms.get(r["kernel"], 0.0) + r["ms"]
             top = max(alone_ms, key=alone_ms.get) if alone_ms else None
             dom_name = top if top in mfma else max(mfma, key=lambda k: mfma[k]["ms"])
-            dom = mfma[dom_name]
+            region = mfma[dom_name]                      # spans inside the timed region (sampled steps)
+            alone = {"launches": 0, "ms": 0.0, "flops": 0.0, "executed": 0.0}
+            for r in (prof_one_stream or []):
+                if r["kernel"] == dom_name:
+                    for k in alone:
+                        alone[k] += r[k]
+            dom = alone if alone["ms"] > 0 else region   # the kernel alone on the chip, where those steps were run
+            dom_steps = 4 if dom is alone else timed_steps
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             executed = dom["executed"] / (dom["ms"] * 1e-3) / 1e12
-            all_flops = sum(v["flops"] for v in mfma.values())
-            all_ms = sum(v["ms"] for v in mfma.values())
+            region_tf = region["flops"] / (region["ms"] * 1e-3) / 1e12
+            mfma_rows = {}
+            for r in (prof_one_stream or prof):
+                if r["flops"] > 0:
+                    f = mfma_rows.setdefault(r["kernel"], {"ms": 0.0, "flops": 0.0})
+                    f["ms"] += r["ms"]
+                    f["flops"] += r["flops"]
+            all_flops = sum(v["flops"] for v in mfma_rows.values())
+            all_ms = sum(v["ms"] for v in mfma_rows.values())
+            all_steps = 4 if prof_one_stream else timed_steps
             traffic_fields = None
             if world == 1 and not args.no_live_traffic:
                 traffic_fields = live_pmc_traffic(dom_name, args)
@@ -705,7 +725,7 @@ def main():
             peak = kernel_peak(dom_name)
             step_peak = PEAK_BF16_MATRIX_TFLOPS / SPLIT_PRODUCTS if args.matrix_path == "split" else PEAK_FP32_MATRIX_TFLOPS
             # every MFMA family priced on its own pipe: sum of (family time at its peak) / sum of measured family time
-            all_ideal_ms = sum(v["flops"] / (kernel_peak(k) * 1e12) * 1e3 for k, v in mfma.items())
+            all_ideal_ms = sum(v["flops"] / (kernel_peak(k) * 1e12) * 1e3 for k, v in mfma_rows.items())
             roofline = {
                 "bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2), "peak": round(peak, 2),
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
@@ -718,19 +738,28 @@ def main():
                 "dominant_by": "one-stream time per step (each launch alone on the chip)" if alone_ms else "time in the timed region",
                 "vs_fp32_instruction_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
                 **traffic_fields,
-                # two clocks for the same family: `avg_launch_ms` = HIP-event span inside the timed region (with a second stream it
-                # includes waiting for CUs the other stream holds); `rocprof_avg_launch_ms` = rocprofv3's kernel duration in the PMC
-                # child pass (every launch alone); either gives a fraction from `flops_per_launch` and `peak`
-                **({"rocprof_frac": round(dom["flops"] / dom["launches"] / (traffic_fields["rocprof_avg_launch_ms"] * 1e-3) / 1e12 / peak, 4),
-                    "clocks": "avg_launch_ms: HIP events in the timed region; rocprof_avg_launch_ms: rocprofv3 kernel trace, launches serialised"}
+                # two clocks for the kernel's duration: `avg_launch_ms` = HIP events with the launch alone on the chip (one-stream steps of
+                # this process); `rocprof_avg_launch_ms` = rocprofv3's kernel duration in the PMC child pass (launches serialised); either
+                # gives a fraction from `flops_per_launch` and `peak`.  `timed_region`: the event SPAN of the same launches inside the timed
+                # region, where the second stream's kernel shares the chip
+                **({"rocprof_frac": round(dom["flops"] / dom["launches"] / (traffic_fields["rocprof_avg_launch_ms"] * 1e-3) / 1e12 / peak, 4)}
                    if traffic_fields.get("rocprof_avg_launch_ms") else {}),
+                "clocks": ("avg_launch_ms: HIP events, " + ("4 fully timed one-stream steps after the timed region (every launch alone on the chip)"
+                                                             if dom is alone else "sampled steps of the timed region") +
+                           "; rocprof_avg_launch_ms: rocprofv3 kernel trace, launches serialised; timed_region.avg_span_ms: HIP events in the timed region"),
                 "flops_per_launch": dom["flops"] / dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
-                "launches": dom["launches"], "sampled_steps": timed_steps,
+                "launches": dom["launches"], "sampled_steps": dom_steps,
+                "timed_region": {"avg_span_ms": round(region["ms"] / region["launches"], 4), "launches": region["launches"], "sampled_steps": timed_steps,
+                                 "achieved": round(region_tf, 2), "frac": round(region_tf / peak, 4),
+                                 "streams": 2 if two_main else 1,
+                                 "note": "event spans of the same launches INSIDE the timed region" +
+                                         ("; with the weight gradients on a second stream a span includes waiting for CUs the other stream's kernel holds"
+                                          if two_main else "")},
                 **({"power_ceiling": power_ceiling,
                     "frac_of_power_ceiling": round(achieved / power_ceiling["tflops"], 4)} if power_ceiling and power_ceiling.get("tflops") and split_dom else {}),
                 "all_mfma_kernels": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
                                      "frac": round(all_ideal_ms / all_ms, 4),
-                                     "ms_per_step": round(all_ms / timed_steps, 3)},
+                                     "ms_per_step": round(all_ms / all_steps, 3)},
                 "model_frac": round(step_flops / (ms_per_step * 1e-3) / 1e12 / step_peak, 4),
                 "model_vs_fp32_instruction_peak": round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 4),
                 **({"pipe": {"instruction": "v_mfma_f32_32x32x16_bf16", "executed_per_algorithmic_flop": SPLIT_PRODUCTS,
@@ -738,7 +767,7 @@ def main():
                              "unit": "TFLOP/s (bf16, executed)",
                              "frac": round(SPLIT_PRODUCTS * (executed if executed > 0 else achieved) / PEAK_BF16_MATRIX_TFLOPS, 4)}}
                    if split_dom else {}),
-                **one_stream_fields(prof_one_stream, dom_name),
+                **one_stream_fields(prof_one_stream, dom_name),   # (the same figures under their name of rounds 2-5)
                 # per family, from the four fully timed ONE-STREAM steps (every launch alone on the chip): the ms_per_step column is
                 # additive and sums to at most the one-stream step; whatever is not event-timed (copies, host gaps) is the remainder
                 "families": family_table(prof_one_stream, 4) if prof_one_stream else family_table(prof, max(1, timed_steps)),

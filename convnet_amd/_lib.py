@@ -150,6 +150,8 @@ def _load():
     sig("convDownMask", None, M, M, M, M, S, S, S, ConvDesc, F, F)
     sig("dotMask", I, M, M, M, M, F, F, F)
     sig("MaxPoolUndoRelu", None, M, M, M, M, S, S, ConvDesc, F)
+    sig("MaxPoolMask", I, M, M, M, S, S, ConvDesc)
+    sig("MaxPoolUndoMask", I, M, M, M, S, S, ConvDesc, F, I)
     sig("convOutpBias", None, M, M, M, M, S, S, S, ConvDesc, F, F)
     for n in ("MaxPoolGemm", "AvgPoolGemm"):
         sig(n, None, M, M, S, S, ConvDesc, F, F)

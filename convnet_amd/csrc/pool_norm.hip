@@ -361,6 +361,120 @@ __global__ void __launch_bounds__(256) pool_undo_max32_block_kernel(const float*
     }
 }
 
+// ---- 3 x 3 stride-2 max pooling with a WINDOW MASK (round 6; MaxPoolMask / MaxPoolUndoMask, include/convnet_hip.h) ---------------------
+// The undo of a max pooling needs the layer's input only to find which inputs equal their window's maximum (every tie counts,
+// cudamat_conv_gemm.cu:220-262): for AlexNet's pool1 that is a 1.19 GB tensor read again, plus the 0.3 GB of maxima, to route 0.3 GB of
+// derivatives.  The forward pass has both in registers: it records, per pooled element, a 16-bit mask — bit 3*dy + dx set when input
+// (dy, dx) of the window is inside the image and EQUAL to the maximum (the same float == the undo kernels apply), bit 9 set when the
+// maximum is positive (what the fused ReLU' of the layer below asks of a matching input: x == max and x > 0  <=>  x == max and max > 0).
+// The undo then reads masks (2 B per pooled element) and derivatives only: pool1 2.98 -> 1.64 GB.  Same 2 x 2 blocks, same candidate
+// order per pixel as pool_fwd_max32_block_kernel / pool_undo_max32_block_kernel: results bit-identical to MaxPool + MaxPoolUndo(Relu).
+// Mask layout: uint16 [c][oy][ox][image] (the pooled tensor's own order), four images = one 8-byte store per lane.
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+__global__ void __launch_bounds__(256) pool_fwd_max32_mask_kernel(const float* __restrict__ in, float* __restrict__ out, u32x2* __restrict__ mask, PoolGeo g) {
+  int bx, by, c;
+  if (!pool_block(g, bx, by, c)) return;
+  const int MB = (g.Mx + 1) >> 1;
+  const int j = bx * 256 + threadIdx.x;
+  if (j >= MB * g.nvec) return;
+  const int xb = j / g.nvec, n = 4 * (j - xb * g.nvec);
+  const int oy0 = 2 * by, ox0 = 2 * xb;
+  const int ys = oy0 * 2 + g.py, xs = ox0 * 2 + g.px;
+  const float* plane = in + (size_t)c * g.H * g.W * g.N + n;
+  f32x4 v[5][5];
+  bool ok[5][5];
+#pragma unroll
+  for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) {
+      const int y = ys + dy, x = xs + dx;
+      ok[dy][dx] = y >= 0 && y < g.H && x >= 0 && x < g.W;
+      const size_t o = ok[dy][dx] ? ((size_t)y * g.W + x) * g.N : 0;
+      v[dy][dx] = *reinterpret_cast<const f32x4*>(plane + o);
+    }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int oy = oy0 + a, ox = ox0 + b;
+      if (oy >= g.My || ox >= g.Mx) continue;
+      f32x4 acc = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[e] = (ok[2 * a + dy][2 * b + dx] && acc[e] < v[2 * a + dy][2 * b + dx][e]) ? v[2 * a + dy][2 * b + dx][e] : acc[e];
+      unsigned m[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        m[e] = acc[e] > 0.f ? 1u << 9 : 0u;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+            m[e] |= (ok[2 * a + dy][2 * b + dx] && v[2 * a + dy][2 * b + dx][e] == acc[e]) ? 1u << (3 * dy + dx) : 0u;
+      }
+      const size_t o = ((size_t)(c * g.My + oy) * g.Mx + ox) * g.N + n;
+      *reinterpret_cast<f32x4*>(out + o) = acc;
+      mask[o >> 2] = u32x2{m[0] | (m[1] << 16), m[2] | (m[3] << 16)};
+    }
+}
+
+__global__ void __launch_bounds__(256) pool_undo_max32_mask_kernel(const float* __restrict__ grads, const u32x2* __restrict__ mask, float* __restrict__ out,
+                                                                   PoolGeo g, float st, bool relu) {
+  int bx, by, c;
+  if (!pool_block(g, bx, by, c)) return;
+  const int WB = (g.W + 1) >> 1;
+  const int j = bx * 256 + threadIdx.x;
+  if (j >= WB * g.nvec) return;
+  const int xb = j / g.nvec, n = 4 * (j - xb * g.nvec);
+  const int iy0 = 2 * by, ix0 = 2 * xb;
+  const int ty0 = iy0 - g.py, tx0 = ix0 - g.px;   // >= 0: py, px are the negated paddings
+  const int oy0 = (ty0 + 1) / 2 - 1, ox0 = (tx0 + 1) / 2 - 1;
+  const size_t pplane = (size_t)c * g.My * g.Mx * g.N + n;
+  f32x4 gv[2][2];
+  unsigned mk[2][2][4];   // per image: the window's mask, reduced to "counts at all" by bit 9 when the ReLU' is fused
+  bool pok[2][2];
+  const unsigned need = relu ? 1u << 9 : 0u;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int oy = oy0 + a, ox = ox0 + b;
+      pok[a][b] = oy >= 0 && oy < g.My && ox >= 0 && ox < g.Mx;
+      const size_t o = pplane + (pok[a][b] ? ((size_t)oy * g.Mx + ox) * g.N : 0);
+      gv[a][b] = *reinterpret_cast<const f32x4*>(grads + o);
+      const u32x2 w = mask[o >> 2];
+      const unsigned m4[4] = {w[0] & 0xffffu, w[0] >> 16, w[1] & 0xffffu, w[1] >> 16};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mk[a][b][e] = (m4[e] & need) == need ? m4[e] : 0u;
+    }
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      if (!(iy0 + dy < g.H && ix0 + dx < g.W)) continue;
+      const int ty = ty0 + dy, tx = tx0 + dx;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int oy = oy0 + a, ox = ox0 + b;
+          const bool cov = pok[a][b] && 2 * oy <= ty && ty < 2 * oy + 3 && 2 * ox <= tx && tx < 2 * ox + 3;
+          const unsigned bit = cov ? 1u << (3 * (ty - 2 * oy) + (tx - 2 * ox)) : 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += (mk[a][b][e] & bit) ? gv[a][b][e] : 0.f;
+        }
+      float* op = out + ((size_t)(c * g.H + iy0 + dy) * g.W + ix0 + dx) * g.N + n;
+      if (st != 0.f) acc = st * *reinterpret_cast<const f32x4*>(op) + acc;
+      *reinterpret_cast<f32x4*>(op) = acc;
+    }
+}
+
 // ---- cross-map response norm --------------------------------------------------------------------------
 // One lane owns 4 consecutive "locations" (a location = one (pixel, image); locations are
 // contiguous in memory) and walks the channel axis with the reference's sliding-window update
@@ -1107,6 +1221,42 @@ void MaxPoolUndo(cudamat* images, cudamat* maxGrads, cudamat* maxActs, cudamat* 
                  ConvDesc d, float scaleTargets) {
   if (park_pool_undo(images, maxGrads, maxActs, targets, images_shape, maxGrads_shape, d, scaleTargets)) return;
   pool_undo<true>(images, maxGrads, maxActs, targets, images_shape, maxGrads_shape, d, scaleTargets);
+}
+// ---- max pooling with a window mask (the kernels' header has the format) ------------------------------------------------------------------
+static bool mask_geo_ok(const PoolGeo& g, const cudamat* images, const cudamat* pooled_a, const cudamat* pooled_b, const cudamat* mask) {
+  const bool vec = g.N % 4 == 0 && a16(images->data_device) && a16(pooled_a->data_device) && (!pooled_b || a16(pooled_b->data_device)) &&
+                   a16(mask->data_device);
+  // (negated paddings: py, px <= 0 is what the 2 x 2-block undo assumes)
+  return fixed_window(g, vec) == 32 && g.py <= 0 && g.px <= 0 && numel(mask) * 2 >= (size_t)g.N * g.C * g.My * g.Mx;
+}
+int MaxPoolMask(cudamat* images, cudamat* targets, cudamat* mask, Shape4D* images_shape, Shape4D* targets_shape, ConvDesc conv_desc) {
+  if (!images->on_device || !targets->on_device || !mask->on_device) return ERROR_NOT_ON_DEVICE;
+  PoolGeo g = pool_geo(images_shape, targets_shape, conv_desc, images, targets);
+  if (!mask_geo_ok(g, images, targets, nullptr, mask)) return ERROR_UNSUPPORTED;
+  KernelTimer timer("pool_fwd_mask_kernel<max>", "pool_fwd", 0.0, (double)g.N * g.C * (4.0 * g.H * g.W + 6.0 * g.My * g.Mx));
+  const int hb = (g.My + 1) / 2;
+  dim3 bgrid(divup(((g.Mx + 1) / 2) * g.nvec, 256), hb, g.C);
+  bgrid = pool_xcd_grid(g, bgrid.x, hb, bgrid);
+  hipLaunchKernelGGL(pool_fwd_max32_mask_kernel, bgrid, dim3(256), 0, stream(), images->data_device, targets->data_device,
+                     reinterpret_cast<u32x2*>(mask->data_device), g);
+  return launch_status();
+}
+int MaxPoolUndoMask(cudamat* maxGrads, cudamat* mask, cudamat* targets, Shape4D* targets_shape, Shape4D* maxGrads_shape, ConvDesc conv_desc,
+                    float scaleTargets, int relu) {
+  if (!maxGrads->on_device || !targets->on_device || !mask->on_device) return ERROR_NOT_ON_DEVICE;
+  // MaxPoolUndoRelu masks the WHOLE result, accumulated target included, by input > 0 — known from the masks only where the input is some
+  // window's maximum: the fused ReLU' is offered for an overwriting undo only
+  if (relu && scaleTargets != 0.f) return ERROR_UNSUPPORTED;
+  PoolGeo g = pool_geo(targets_shape, maxGrads_shape, conv_desc, targets, maxGrads);
+  if (!mask_geo_ok(g, targets, maxGrads, nullptr, mask)) return ERROR_UNSUPPORTED;
+  KernelTimer timer("pool_undo_mask_kernel<max>", "pool_undo", 0.0,
+                    (double)g.N * g.C * ((scaleTargets != 0.f ? 8.0 : 4.0) * g.H * g.W + 6.0 * g.My * g.Mx));
+  const int hb = (g.H + 1) / 2;
+  dim3 bgrid(divup(((g.W + 1) / 2) * g.nvec, 256), hb, g.C);
+  bgrid = pool_xcd_grid(g, bgrid.x, hb, bgrid);
+  hipLaunchKernelGGL(pool_undo_max32_mask_kernel, bgrid, dim3(256), 0, stream(), maxGrads->data_device,
+                     reinterpret_cast<const u32x2*>(mask->data_device), targets->data_device, g, scaleTargets, relu != 0);
+  return launch_status();
 }
 void AvgPoolUndoGemm(cudamat* avgGrads, cudamat* targets, Shape4D* avgGrads_shape, Shape4D* targets_shape, ConvDesc d, float scaleTargets) {
   pool_undo<false>(nullptr, avgGrads, nullptr, targets, targets_shape, avgGrads_shape, d, scaleTargets);

@@ -615,16 +615,38 @@ class _PoolEdge(Edge):
 
 
 class MaxPoolEdge(_PoolEdge):
-    """src/maxpool_edge.{h,cc}"""
+    """src/maxpool_edge.{h,cc}.  With the host's fused entry points on (ConvNet(fused=True) sets ``fused``) the forward pass also records
+    the window masks (include/convnet_hip.h: MaxPoolMask) and the backward pass routes the derivatives from them alone — it reads neither
+    the layer's input (1.19 GB for AlexNet's pool1) nor its maxima.  Bit-identical to the reference's call pair; geometries without a mask
+    kernel, and a ComputeDown that is handed other matrices than the ComputeUp before it, take the reference's calls."""
     can_fuse_mask = True
+
+    def __init__(self, c):
+        super().__init__(c)
+        self.fused = False
+        self.mask_ = None
+        self.mask_for_ = None   # (input data pointer, output data pointer, batch) of the ComputeUp that wrote mask_
 
     def ComputeUp(self, input, output, overwrite, train=True, fuse_relu=None):
         if not overwrite:
             raise SystemExit(" In MaxPoolEdge::ComputeUp() : some other layer is writing to this maxpool layer's output as well. Not implemented.")
+        self.mask_for_ = None
+        if self.fused and train:
+            need = (output.GetRows(), (output.GetCols() + 1) // 2)
+            if self.mask_ is None or (self.mask_.GetRows(), self.mask_.GetCols()) != need:
+                self.mask_ = Matrix()
+                self.mask_.AllocateGPUMemory(need[0], need[1], "maxpool mask")
+            if Matrix.ConvMaxPoolMask(input, output, self.mask_, self.conv_desc_):
+                self.mask_for_ = (input.mat_.data_device, output.mat_.data_device, output.GetRows())
+                return
         Matrix.ConvMaxPool(input, output, self.conv_desc_)
 
     def ComputeDown(self, deriv_output, input, output, deriv_input, overwrite, fuse_mask=None):
-        if fuse_mask is not None and fuse_mask == 1.0:
+        relu = fuse_mask is not None and fuse_mask == 1.0
+        if self.mask_for_ is not None and self.mask_for_ == (input.mat_.data_device, output.mat_.data_device, output.GetRows()) and (overwrite or not relu):
+            Matrix.ConvMaxPoolUndoMask(deriv_output, self.mask_, deriv_input, self.conv_desc_, 0 if overwrite else 1, relu)
+            return
+        if relu:
             Matrix.ConvMaxPoolUndoRelu(input, deriv_output, output, deriv_input, self.conv_desc_, 0 if overwrite else 1)
             return
         Matrix.ConvMaxPoolUndo(input, deriv_output, output, deriv_input, self.conv_desc_, 0 if overwrite else 1)

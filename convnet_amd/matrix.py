@@ -456,6 +456,19 @@ class Matrix:
         lib.MaxPoolGemm(input.GetMat(), output.GetMat(), ctypes.byref(input.shape_), ctypes.byref(output.shape_), conv_desc, 0.0, 1.0)
 
     @staticmethod
+    def ConvMaxPoolMask(input, output, mask, conv_desc):
+        """MaxPool that also records the window masks (include/convnet_hip.h: MaxPoolMask).  False: this geometry has no mask kernel and
+        nothing was computed — call ConvMaxPool."""
+        if not hasattr(lib, "MaxPoolMask"):   # (an older build of the library under CONVNET_HIP_LIB)
+            return False
+        return lib.MaxPoolMask(input.GetMat(), output.GetMat(), mask.GetMat(), ctypes.byref(input.shape_), ctypes.byref(output.shape_), conv_desc) == 0
+
+    @staticmethod
+    def ConvMaxPoolUndoMask(deriv_output, mask, deriv_input, conv_desc, scale_targets, relu):
+        _chk(lib.MaxPoolUndoMask(deriv_output.GetMat(), mask.GetMat(), deriv_input.GetMat(), ctypes.byref(deriv_input.shape_),
+                                 ctypes.byref(deriv_output.shape_), conv_desc, float(scale_targets), int(bool(relu))), "MaxPoolUndoMask")
+
+    @staticmethod
     def ConvMaxPoolUndo(input, deriv_output, output, deriv_input, conv_desc, scale_targets):
         lib.MaxPoolUndoGemm(input.GetMat(), deriv_output.GetMat(), output.GetMat(), deriv_input.GetMat(),
                             ctypes.byref(input.shape_), ctypes.byref(deriv_output.shape_), conv_desc, float(scale_targets))

@@ -339,6 +339,19 @@ int dotMask(cudamat* mat1, cudamat* mat2, cudamat* state, cudamat* target, float
 void MaxPoolUndoRelu(cudamat* images, cudamat* maxGrads, cudamat* maxActs, cudamat* targets,
                      Shape4D* images_shape, Shape4D* maxGrads_shape, ConvDesc conv_desc,
                      float scaleTargets);
+/* MaxPoolEdge::ComputeUp / ComputeDown (src/maxpool_edge.cc:27-45) with a window mask instead of a second pass over the layer's input:
+ * MaxPoolMask = MaxPool (scaleTargets 0, scaleOutput 1) that ALSO writes, per pooled element, 16 bits into `mask`: bit 3*dy + dx set when
+ * input (dy, dx) of its window lies inside the image and equals the maximum (float ==, every tie: what kMaxPoolUndo tests,
+ * cudamat_conv_gemm.cu:220-262), bit 9 set when the maximum is > 0.  `mask` is any device matrix of at least numel(targets) / 2 floats,
+ * 16-byte aligned, laid out as uint16 in the pooled tensor's own element order.  MaxPoolUndoMask = MaxPoolUndo (relu == 0) or
+ * MaxPoolUndoRelu (relu != 0) computed from (maxGrads, mask) alone — neither the layer's input nor its maxima are read — and bit-identical
+ * to them as long as `mask` is what MaxPoolMask wrote for the tensors the undo would have been given.  3 x 3 windows, stride 2,
+ * padding >= 0, N % 4 == 0 only, and relu != 0 only with scaleTargets == 0 (MaxPoolUndoRelu masks the accumulated target too, by
+ * input > 0, which the masks hold only for inputs that are a maximum): anything else returns ERROR_UNSUPPORTED and touches nothing
+ * (call MaxPool / MaxPoolUndo / MaxPoolUndoRelu). */
+int MaxPoolMask(cudamat* images, cudamat* targets, cudamat* mask, Shape4D* images_shape, Shape4D* targets_shape, ConvDesc conv_desc);
+int MaxPoolUndoMask(cudamat* maxGrads, cudamat* mask, cudamat* targets, Shape4D* targets_shape, Shape4D* maxGrads_shape,
+                    ConvDesc conv_desc, float scaleTargets, int relu);
 /* ResponseNormEdge::ComputeUp + the ReLU of a RECTIFIED_LINEAR destination layer (layer.cc:549) in one pass. */
 void ResponseNormCrossMapRelu(cudamat* images, cudamat* targets, int numFilters, int sizeF,
                               float addScale, float powScale, bool blocked);

@@ -371,6 +371,30 @@ static void pool_case(int N, int C, int H, int K, int st) {
               " s" + std::to_string(st),
           std::max(e1, e2), true);
 }
+// MaxPoolMask + MaxPoolUndoMask (3 x 3 stride 2) against the oracle's MaxPool + MaxPoolUndo; quantised inputs: every window holds ties
+static void pool_mask_case(int N, int C, int H) {
+  const int K = 3, st = 2, M = (H - K) / st + 1;
+  Geo g{N, C, H, H, C, K, K, st, st, 0};
+  auto xv = rnd((size_t)C * H * H * N, 35), yv = rnd((size_t)C * M * M * N, 36), gv = rnd((size_t)C * M * M * N, 37), dv = rnd((size_t)C * H * H * N, 38);
+  for (float& v : xv) v = std::floor(2.f * v);
+  std::vector<float> mv((size_t)C * M * M * N / 2 + 8);
+  float *x = al16(xv), *y = al16(yv), *gr = al16(gv), *dx = al16(dv), *mk = al16(mv);
+  std::vector<float> yr((size_t)C * M * M * N), dr((size_t)C * H * H * N);
+  cudamat mx = mat(x, N, H * H * C), my = mat(y, N, M * M * C), mg = mat(gr, N, M * M * C), md = mat(dx, N, H * H * C), mm = mat(mk, N, M * M * C / 2);
+  Shape4D sx{{N, H, H, C}}, sy{{N, M, M, C}};
+  const int rc1 = MaxPoolMask(&mx, &my, &mm, &sx, &sy, desc(g));
+  oracle_max_pool(x, yr.data(), N, C, H, H, K, K, st, st, 0, 0, M, M, 0.f, 1.f);
+  const double e1 = rel_err_f(y, yr.data(), yr.size());
+  const int rc2 = MaxPoolUndoMask(&mg, &mm, &md, &sx, &sy, desc(g), 0.f, 0);
+  oracle_max_pool_undo(x, gr, yr.data(), dr.data(), N, C, H, H, K, K, st, st, 0, 0, M, M, 0.f);
+  const double e2 = rel_err_f(dx, dr.data(), dr.size());
+  // ... and with the ReLU' of the layer below fused: the derivative survives where the input itself is positive
+  const int rc3 = MaxPoolUndoMask(&mg, &mm, &md, &sx, &sy, desc(g), 0.f, 1);
+  for (size_t i = 0; i < dr.size(); ++i) dr[i] = x[i] > 0.f ? dr[i] : 0.f;
+  const double e3 = rel_err_f(dx, dr.data(), dr.size());
+  verdict("abi MaxPoolMask + MaxPoolUndoMask N" + std::to_string(N) + " C" + std::to_string(C) + " " + std::to_string(H) + "x" + std::to_string(H),
+          std::max(e1, std::max(e2, e3)), rc1 == 0 && rc2 == 0 && rc3 == 0);
+}
 static void rnorm_case(int N, int C, int HW, int sizeF) {
   const int locs = HW * N;
   auto xv = rnd((size_t)C * locs, 41), yv = rnd((size_t)C * locs, 42), gv = rnd((size_t)C * locs, 43), dv = rnd((size_t)C * locs, 44);
@@ -413,6 +437,8 @@ int main(int argc, char** argv) {
       pool_case(32, 32, 21, 3, 2);        // pool1 type (3 x 3 stride 2; 441 pixels: the 2 x 2-block undo kernel)
       pool_case(64, 16, 7, 3, 2);         // a small map: the per-output undo kernel
       pool_case(32, 8, 43, 3, 2);         // 21 x 21 outputs: the 2 x 2-block forward kernel with an odd last row and column
+      pool_mask_case(32, 8, 21);          // the mask pair: 10 x 10 windows on a 21 x 21 map, every window with ties
+      pool_mask_case(16, 4, 12);          // even map: the last input row and column lie outside every window
       rnorm_case(32, 96, 25, 5);          // rnorm1 type: 96 channels, window 5
       rnorm_case(16, 256, 9, 5);
       rnorm_case(32, 96, 9, 24);          // rnorm1 itself: window 24 = the fast kernels' 6-channel segments

@@ -46,7 +46,13 @@ def main():
         d = make_conv_desc(C, C, K, K, s, s, p, p)
         x, dx, y, dy = mat(N, C, H), mat(N, C, H), mat(N, C, M), mat(N, C, M)
         big, small = 4.0 * N * C * H * H, 4.0 * N * C * M * M
+        mk = Matrix()
+        mk.AllocateGPUMemory(N, (M * M * C + 1) // 2)
+        masked = K == 3 and s == 2
         for tag, fn, nbytes in (("fwd", lambda: Matrix.ConvMaxPool(x, y, d), big + small),
+                                *(((("fwd+mask", lambda: Matrix.ConvMaxPoolMask(x, y, mk, d), big + 1.5 * small),
+                                    ("undo(mask)", lambda: Matrix.ConvMaxPoolUndoMask(dy, mk, dx, d, 0, False), big + 1.5 * small),
+                                    ("undo(mask)+relu", lambda: Matrix.ConvMaxPoolUndoMask(dy, mk, dx, d, 0, True), big + 1.5 * small))) if masked else ()),
                                 ("undo", lambda: Matrix.ConvMaxPoolUndo(x, dy, y, dx, d, 0), 2 * big + 2 * small),
                                 ("undo+relu", lambda: Matrix.ConvMaxPoolUndoRelu(x, dy, y, dx, d, 0), 2 * big + 2 * small)):
             for r in timed(fn, args.reps):
