@@ -433,6 +433,9 @@ int main(int argc, char** argv) {
       abi_conv_case(Geo{64, 128, 9, 9, 32, 3, 3, 1, 1, 1}, "down");    // one stride class
       abi_conv_case(Geo{64, 96, 11, 11, 32, 5, 5, 2, 2, 0}, "down");   // conv2 type: four stride classes in one launch
       abi_conv_case(Geo{32, 3, 15, 15, 96, 7, 7, 2, 2, 1}, "outp");    // conv1 type: the 160 x 96 tile of 16 x 16 MFMAs, bias row in a padding row
+      abi_conv_case(Geo{96, 3, 21, 17, 80, 7, 7, 2, 2, 1}, "outp");    // ... three image chunks per pixel, rectangular, 80 of 96 filters
+      abi_conv_case(Geo{32, 5, 15, 19, 96, 4, 7, 2, 2, 1}, "outp");    // ... 5 channels x 4 x 7 taps (20 bands, K = 140)
+      abi_conv_case(Geo{32, 3, 12, 12, 96, 7, 7, 1, 1, 3}, "outp");    // ... stride 1, three columns of padding on either side
       abi_dot_case(64, 256, 128);
       pool_case(32, 32, 21, 3, 2);        // pool1 type (3 x 3 stride 2; 441 pixels: the 2 x 2-block undo kernel)
       pool_case(64, 16, 7, 3, 2);         // a small map: the per-output undo kernel

@@ -103,3 +103,37 @@ def test_other_shapes_stay_on_the_gather_kernels(hip):
         got = hip.conv_up(g, x, w)
         assert last_kernel() == "gg_kernel(fprop)", (g, last_kernel())
         assert rel_err(got, oracle.port.conv_up(g, x, w)) < TOL
+
+
+# ---- the weight gradient of the same layer class: wg_kernel's 160 x 96 tile of 16 x 16 MFMAs (gather_gemm.hip) -----------------------------
+# Against the CPU oracle (the reference's conv_outp, cudamat_conv_gemm.cu:827-960) with the bias row riding along, on geometries chosen
+# for the walk of the reduction: several image chunks per pixel, a ragged last chunk, rectangular maps, wide padding, other tap shapes,
+# slab ranges that begin in the middle of an output row.  (Round 6 tried a patch-resident A operand for this tile — a ring of input
+# columns, 42 staged rows per pixel instead of 147; parity green on these cases at the first run, 16 % SLOWER: the tile is bound by the
+# split arithmetic of its wave, not by staging — profiles/r06_conv1_wgrad_ring.txt — and the build was removed.)
+WGRAD_CASES = [
+    Geom(N=32, C=3, H=31, W=31, F=96, Ky=7, Kx=7, sy=2, sx=2, pady=1, padx=1),     # one image chunk, 14 x 14 outputs
+    Geom(N=96, C=3, H=21, W=45, F=80, Ky=7, Kx=7, sy=2, sx=2, pady=3, padx=3),     # three image chunks per pixel, rectangular, wide padding, 80 of 96 filters
+    Geom(N=44, C=3, H=25, W=25, F=96, Ky=7, Kx=7, sy=2, sx=2),                     # N % 32 != 0: the second chunk is 12 images; no padding
+    Geom(N=64, C=5, H=15, W=19, F=96, Ky=4, Kx=7, sy=2, sx=2, pady=1, padx=1),     # 5 channels x 4 x 7 taps: K = 140
+    Geom(N=32, C=3, H=12, W=12, F=96, Ky=7, Kx=7, pady=3, padx=3),                 # stride 1
+    Geom(N=256, C=3, H=63, W=63, F=96, Ky=7, Kx=7, sy=2, sx=2, pady=1, padx=1),    # 30 x 30 outputs x 8 chunks = 7 200 chunks over ~500 blocks
+]
+
+
+@pytest.mark.parametrize("g", WGRAD_CASES, ids=_id)
+def test_fewc_wgrad_vs_oracle(hip, g):
+    from convnet_amd import _lib
+    from hip_adapter import conv_outp_bias
+    rng = np.random.default_rng(54)
+    x, dy = rnd(rng, g.in_shape()), rnd(rng, g.out_shape())
+    dw0, db0 = rnd(rng, g.filt_shape()), rnd(rng, (g.F,))
+    for st, so in ((0.0, 1.0), (1.0, 0.5)):
+        _lib.profile_enable(True)
+        dw, db = conv_outp_bias(g, x, dy, dw0.copy(), db0.copy(), st, so)
+        names = [r["kernel"] for r in _lib.profile_report()]
+        _lib.profile_enable(False)
+        assert any(n.startswith("wg_kernel<2,2,5,3,x16") for n in names), names
+        assert rel_err(dw, oracle.port.conv_outp(g, x, dy, dw0.copy(), st, so)) < TOL
+        ref_db = st * db0 + so * dy.reshape(g.F, -1).astype(np.float64).sum(axis=1)
+        assert rel_err(db, ref_db.astype(np.float32)) < TOL
