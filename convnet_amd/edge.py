@@ -7,6 +7,7 @@ Local / one-to-one / up-down-sample / RGB->YUV edges are out of hot-path scope (
 gradient); the unfused path issues exactly the reference's Matrix-call sequence.
 """
 import math
+import os
 
 from ._lib import ConvDesc
 from .matrix import Matrix
@@ -614,6 +615,9 @@ class _PoolEdge(Edge):
         self.num_modules_y_, self.num_modules_x_, self.num_modules_t_ = Edge.GetNumModules(d, y, x, t)
 
 
+_POOL_MASK = os.environ.get("CONVNET_POOL_MASK", "1") != "0"   # A/B switch (tools/profile_round.sh): 0 = the reference's call pair on the fused path too
+
+
 class MaxPoolEdge(_PoolEdge):
     """src/maxpool_edge.{h,cc}.  With the host's fused entry points on (ConvNet(fused=True) sets ``fused``) the forward pass also records
     the window masks (include/convnet_hip.h: MaxPoolMask) and the backward pass routes the derivatives from them alone — it reads neither
@@ -631,7 +635,7 @@ class MaxPoolEdge(_PoolEdge):
         if not overwrite:
             raise SystemExit(" In MaxPoolEdge::ComputeUp() : some other layer is writing to this maxpool layer's output as well. Not implemented.")
         self.mask_for_ = None
-        if self.fused and train:
+        if self.fused and train and _POOL_MASK:
             need = (output.GetRows(), (output.GetCols() + 1) // 2)
             if self.mask_ is None or (self.mask_.GetRows(), self.mask_.GetCols()) != need:
                 self.mask_ = Matrix()

@@ -78,7 +78,12 @@ typedef struct ConvDesc {
 /* ---- library state (new; the reference used the legacy default stream + per-call cudaMalloc) ---
  * All work is enqueued on ONE current stream per host thread-less global (the reference is not
  * thread-safe either).  Scratch (split-K partials, dgrad filter images) comes from a
- * library-owned arena that only grows; nothing in the ABI passes a workspace. */
+ * library-owned arena that only grows; nothing in the ABI passes a workspace.
+ * ONE DEVICE PER PROCESS (the reference's model: one process per GPU, src/convnet_cpu.cc / src/convnet.cc:407-450 over MPI ranks).  The
+ * zero page, the scratch arenas, the launch settings cached per kernel (hipFuncSetAttribute, occupancy, CU count) and the wide kernels'
+ * slot counts are process-wide and belong to the device that was current at the first call; cuda_set_device to ANOTHER device after
+ * work has been issued is not supported (the tables that ARE keyed by device — the generic-k table, the exchange's stream and events —
+ * do not change that). */
 int convnet_hip_init(int device_id);                 /* cuda_set_device + cublas_init (cudamat.cuh:93-96) */
 void convnet_hip_shutdown(void);                     /* cublas_shutdown */
 void convnet_hip_set_stream(void* hip_stream);       /* hipStream_t; NULL = default stream */

@@ -3,8 +3,9 @@
 #   bench line (roofline with LIVE PMC traffic + cpu_baseline + ref_host), rocprofv3 kernel-trace stats of the same command, the two PMC
 #   traffic passes of the whole step (FETCH_SIZE and WRITE_SIZE separately — together they need 5 of the 4 TCC slots), matrix-pipe
 #   counters of conv4, per-layer table, the per-GPU batch sweep of strong scaling, the split-path arithmetic table, DP self-tests.
-# Usage: /usr/local/graft/bin/gpurun --timeout 1700 -- 'bash tools/profile_round.sh r04'
+# Usage: /usr/local/graft/bin/gpurun --timeout 1700 -- 'bash tools/profile_round.sh r06 r05'
 TAG=${1:-rXX}
+PREV=${2:-r05}   # the previous round's library for the same-call A/B: convnet_amd/lib/libconvnet_hip_$PREV.so
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/profile_$TAG
 mkdir -p "$O"; cd "$R" || exit 1
@@ -13,18 +14,16 @@ echo "== bench (default flags: what the driver runs)"
 timeout 500 python bench.py > "$O/bench_n1.json" 2> "$O/bench_n1.err"; echo "rc=$?"; cut -c1-230 "$O/bench_n1.json"
 echo "== one-stream bench"
 timeout 200 python bench.py --no-overlap-wgrad --no-side-stream-update $Q > "$O/bench_n1_one_stream.json" 2>/dev/null; cut -c60-160 "$O/bench_n1_one_stream.json"
-echo "== same-call A/B against the previous round's library (convnet_amd/lib/libconvnet_hip_r04.so, tools/build_prev_lib.sh), where it is present"
-if [ -f convnet_amd/lib/libconvnet_hip_r04.so ]; then
-  for i in 1 2; do
-    CONVNET_HIP_LIB=libconvnet_hip_r04.so timeout 200 python bench.py $Q > "$O/bench_n1_r04lib_run$i.json" 2>/dev/null; echo "r04 lib: $(cut -c60-175 "$O/bench_n1_r04lib_run$i.json")"
+echo "== same-call A/B against the previous round's library (convnet_amd/lib/libconvnet_hip_$PREV.so), where it is present"
+if [ -f convnet_amd/lib/libconvnet_hip_$PREV.so ]; then
+  for i in 1 2 3; do
+    CONVNET_HIP_LIB=libconvnet_hip_$PREV.so timeout 200 python bench.py $Q > "$O/bench_n1_${PREV}lib_run$i.json" 2>/dev/null; echo "$PREV lib: $(cut -c60-175 "$O/bench_n1_${PREV}lib_run$i.json")"
     timeout 200 python bench.py $Q > "$O/bench_n1_now_run$i.json" 2>/dev/null; echo "now    : $(cut -c60-175 "$O/bench_n1_now_run$i.json")"
   done
-  CONVNET_HIP_LIB=libconvnet_hip_r04.so timeout 120 python tools/layer_bench.py > "$O/layer_bench_r04lib.txt" 2>&1
+  CONVNET_HIP_LIB=libconvnet_hip_$PREV.so timeout 120 python tools/layer_bench.py > "$O/layer_bench_${PREV}lib.txt" 2>&1
 fi
-echo "== kernel choices of this round, same call: round-4 kernels (patch 0, wgrad tile 0, no gfc) against the defaults"
-CONVNET_GG_PATCH=0 CONVNET_WG_TILE=0 CONVNET_GG_FEWC=0 timeout 120 python tools/layer_bench.py --only conv > "$O/layer_bench_r04_kernels.txt" 2>&1
-grep -h "conv[1-5].*_kernel<" "$O/layer_bench_r04_kernels.txt" | grep -v "planes\|reduce\|tail_fix" | head -20
-for v in "0 0 0" "3 1 1"; do set -- $v; CONVNET_GG_PATCH=$1 CONVNET_WG_TILE=$2 CONVNET_GG_FEWC=$3 timeout 200 python bench.py --steps 20 --warmup 5 $Q > "$O/bench_kernels_p$1_w$2_f$3.json" 2>/dev/null; echo "patch=$1 wgrad_tile=$2 fewc=$3: $(cut -c60-175 "$O/bench_kernels_p$1_w$2_f$3.json")"; done
+echo "== this round's choices one at a time, same call: pooling masks off (CONVNET_POOL_MASK=0), response-norm fast kernels off (CONVNET_RNORM_FAST=0)"
+for v in "CONVNET_POOL_MASK=0" "CONVNET_RNORM_FAST=0" "CONVNET_POOL_MASK=1"; do env $v timeout 200 python bench.py --steps 20 --warmup 5 $Q > "$O/bench_choice_$v.json" 2>/dev/null; echo "$v: $(cut -c60-175 "$O/bench_choice_$v.json")"; done
 echo "== per-layer table"
 timeout 120 python tools/layer_bench.py > "$O/layer_bench.txt" 2>&1; grep -v amdgpu "$O/layer_bench.txt" | head -60
 timeout 120 python tools/pool_bench.py > "$O/pool_bench.txt" 2>&1
