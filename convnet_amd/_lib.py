@@ -195,6 +195,7 @@ def _load():
     sig("softmax_ce_grad_correct", I, M, M, M, M, M, F)
     sig("sgd_momentum_step", I, M, M, M, F, F, F, F)
     sig("sgd_momentum_step_normlimit", I, M, M, M, F, F, F, F, F, I)
+    sig("sgd_momentum_step_multi", I, I, P(M), P(M), P(M), c_float_p, c_float_p, c_float_p, c_float_p)
     R = P(rnd_struct)
     sig("init_random", I, R, I)
     sig("fill_with_rand", I, R, M)

@@ -417,12 +417,19 @@ class ConvNet(TrainLoopMixin):
             torch.cuda.current_stream().wait_event(done)   # weight gradients (and side-stream updates) are in
             if self.overlap_update_:
                 return
+        # fused host: the plain SGD steps of every edge (AlexNet: five convolution banks and eight biases) leave as ONE launch behind the loop
+        batch = [] if self.fused else None
         for e in self.edges_:
             if e.IsBackPropBlocked():
                 continue
             if self.exchange_ is not None and e in self.edge_slices_:
                 self.exchange_.WaitFor(e)       # the averaged gradient slice has arrived
-            e.UpdateWeights()
+            if batch is not None and isinstance(e, EdgeWithWeight):
+                e.UpdateWeights(batch)
+            else:
+                e.UpdateWeights()
+        if batch:
+            Matrix.SGDMomentumStepMulti(batch)
 
     # ---- data -------------------------------------------------------------------------------------------
     def SetupDataset(self, dataset):

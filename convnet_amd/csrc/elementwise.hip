@@ -590,9 +590,8 @@ __device__ __forceinline__ void sgd_one(float& g, float& w, float& h, float l2, 
   w = w - h;
 }
 
-__global__ void sgd_kernel(float* __restrict__ g, float* __restrict__ w, float* __restrict__ h, size_t n, bool vec, float l2, float clip,
-                           float eps, float mom) {
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+__device__ __forceinline__ void sgd_range(float* __restrict__ g, float* __restrict__ w, float* __restrict__ h, size_t n, bool vec, float l2, float clip,
+                                          float eps, float mom, size_t tid, size_t stride) {
   size_t done = 0;
   if (vec) {
     const size_t n4 = n >> 2;
@@ -611,6 +610,28 @@ __global__ void sgd_kernel(float* __restrict__ g, float* __restrict__ w, float* 
     done = n4 << 2;
   }
   for (size_t i = done + tid; i < n; i += stride) sgd_one(g[i], w[i], h[i], l2, clip, eps, mom);
+}
+__global__ void sgd_kernel(float* __restrict__ g, float* __restrict__ w, float* __restrict__ h, size_t n, bool vec, float l2, float clip,
+                           float eps, float mom) {
+  sgd_range(g, w, h, n, vec, l2, clip, eps, mom, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+}
+// Several tensors in ONE launch (sgd_momentum_step_multi): AlexNet's step updates 13 small tensors (the convolution banks and every
+// bias) with ~7 us launches of a few MB each; blockIdx.y picks the tensor, every tensor with its own hyper-parameters.  Same sgd_one per
+// element: bit-identical to one sgd_momentum_step per tensor.
+constexpr int kSgdMulti = 16;
+struct SgdItem {
+  float *g, *w, *h;
+  unsigned long long n;
+  float l2, clip, eps, mom;
+  int vec, pad_;
+};
+struct SgdBatch {
+  SgdItem it[kSgdMulti];
+};
+__global__ void sgd_multi_kernel(const SgdBatch b) {
+  const SgdItem& t = b.it[blockIdx.y];
+  sgd_range(t.g, t.w, t.h, (size_t)t.n, t.vec != 0, t.l2, t.clip, t.eps, t.mom, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
+            (size_t)gridDim.x * blockDim.x);
 }
 
 }  // namespace chip
@@ -804,6 +825,36 @@ int sgd_momentum_step(cudamat* grad, cudamat* param, cudamat* history, float l2_
   KernelTimer timer("sgd_kernel", "sgd", 0.0, 20.0 * n);   // reads g, w, h; writes h, w (>= 20 bytes per parameter)
   hipLaunchKernelGGL(sgd_kernel, dim3(blocks_for(n / 4 + 1)), dim3(kThreads), 0, stream(), grad->data_device, param->data_device,
                      history->data_device, n, vec, l2_decay, gradient_clip, epsilon, momentum);
+  return launch_status();
+}
+
+// sgd_momentum_step on `count` tensors, each with its own hyper-parameters, in ceil(count / 16) launches
+int sgd_momentum_step_multi(int count, cudamat** grads, cudamat** params, cudamat** histories, const float* l2_decay, const float* gradient_clip,
+                            const float* epsilon, const float* momentum) {
+  if (count < 0 || (count > 0 && (!grads || !params || !histories || !l2_decay || !gradient_clip || !epsilon || !momentum))) return ERROR_GENERIC;
+  for (int i = 0; i < count; ++i) {
+    if (!grads[i]->on_device || !params[i]->on_device || !histories[i]->on_device) return ERROR_NOT_ON_DEVICE;
+    if (numel(grads[i]) != numel(params[i]) || numel(histories[i]) != numel(params[i])) return ERROR_INCOMPATIBLE_DIMENSIONS;
+  }
+  for (int base = 0; base < count; base += kSgdMulti) {
+    SgdBatch b{};
+    int m = 0;
+    size_t most = 0, total = 0;
+    for (int i = base; i < count && i < base + kSgdMulti; ++i) {
+      const size_t n = numel(params[i]);
+      if (n == 0) continue;
+      SgdItem& t = b.it[m++];
+      t.g = grads[i]->data_device; t.w = params[i]->data_device; t.h = histories[i]->data_device;
+      t.n = n;
+      t.l2 = l2_decay[i]; t.clip = gradient_clip[i]; t.eps = epsilon[i]; t.mom = momentum[i];
+      t.vec = al16(t.g) && al16(t.w) && al16(t.h);
+      most = n > most ? n : most;
+      total += n;
+    }
+    if (m == 0) continue;
+    KernelTimer timer("sgd_multi_kernel", "sgd", 0.0, 20.0 * total);
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(blocks_for(most / 4 + 1), m), dim3(kThreads), 0, stream(), b);
+  }
   return launch_status();
 }
 

@@ -268,16 +268,23 @@ class EdgeWithWeight(Edge):
             if self.bias_optimizer_.IsAllocated():
                 self.bias_optimizer_.LoadParameters(file, f"{edge_name}:bias")
 
-    def UpdateWeights(self):
-        # src/edge_with_weight.cc:96-106
+    def UpdateWeights(self, batch=None):
+        # src/edge_with_weight.cc:96-106.  `batch`: a list that collects the plain fused SGD steps of a whole net for ONE launch
+        # (ConvNet.UpdateWeights -> Matrix.SGDMomentumStepMulti); steps that are not plain run here as before.
         if self.is_tied_:
             return
         if self.num_grads_received_ < self.num_shares_:
             raise SystemExit("Error: Update called when all gradients were not received.")
         self.num_grads_received_ = 0
-        self.weight_optimizer_.Optimize(self.grad_weights_, self.weights_)
+        pairs = [(self.weight_optimizer_, self.grad_weights_, self.weights_)]
         if not self.has_no_bias_:
-            self.bias_optimizer_.Optimize(self.grad_bias_, self.bias_)
+            pairs.append((self.bias_optimizer_, self.grad_bias_, self.bias_))
+        for opt, grad, param in pairs:
+            item = opt.PlanFusedStep(grad, param) if batch is not None and hasattr(opt, "PlanFusedStep") else None
+            if item is not None:
+                batch.append(item)
+            else:
+                opt.Optimize(grad, param)
 
     def NotifyStart(self):
         self.weight_optimizer_.NotifyStart(self.weights_)

@@ -516,6 +516,22 @@ class Matrix:
                                    float(epsilon), float(momentum)), "sgd step")
 
     @staticmethod
+    def SGDMomentumStepMulti(items):
+        """items: (grad, param, history, l2_decay, gradient_clip, epsilon, momentum) per tensor — sgd_momentum_step on all of them in one
+        launch per 16 (include/convnet_hip.h: sgd_momentum_step_multi); an older build of the library gets one call per tensor."""
+        if not items:
+            return
+        if not hasattr(lib, "sgd_momentum_step_multi") or len(items) == 1:
+            for it in items:
+                Matrix.SGDMomentumStep(*it)
+            return
+        n = len(items)
+        MP = ctypes.POINTER(_lib.cudamat)
+        arr = lambda k: (MP * n)(*[ctypes.pointer(it[k].mat_) for it in items])   # noqa: E731
+        flt = lambda k: (ctypes.c_float * n)(*[float(it[k]) for it in items])    # noqa: E731
+        _chk(lib.sgd_momentum_step_multi(n, arr(0), arr(1), arr(2), flt(3), flt(4), flt(5), flt(6)), "sgd step (multi)")
+
+    @staticmethod
     def SGDMomentumStepNormLimit(grad, param, history, l2_decay, gradient_clip, epsilon, momentum, norm, constraint):
         _chk(lib.sgd_momentum_step_normlimit(grad.GetMat(), param.GetMat(), history.GetMat(), float(l2_decay), float(gradient_clip),
                                              float(epsilon), float(momentum), float(norm), int(bool(constraint))), "sgd step + norm limit")

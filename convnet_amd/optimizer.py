@@ -147,6 +147,17 @@ class SGDOptimizer(Optimizer):
             self.gradient_history_.Mult(self.GetMomentum())
             parameter.Add(self.gradient_history_, -1)
 
+    def PlanFusedStep(self, gradient, parameter):
+        """The plain fused step of Optimize as DATA — (gradient, parameter, history, l2, clip, epsilon, momentum) for
+        Matrix.SGDMomentumStepMulti — with the step counter advanced exactly as Optimize would; None when this optimizer's step is not the
+        plain one (unfused host, Nesterov, a norm limit / constraint, still before start_optimization_after): the caller runs Optimize."""
+        if (not self.fused or self.nesterov_momentum_ or self.weight_norm_constraint_ > 0 or self.weight_norm_limit_ > 0 or
+                self.step_ < self.start_optimization_after_):
+            return None
+        item = (gradient, parameter, self.gradient_history_, self.l2_decay_, self.gradient_clip_, self.GetDecayedEpsilon(), self.GetMomentum())
+        self.step_ += 1
+        return item
+
     def Optimize(self, gradient, parameter):
         # src/optimizer.cc:174-200
         if self.step_ >= self.start_optimization_after_:

@@ -327,7 +327,12 @@ int sgd_momentum_step(cudamat* grad, cudamat* param, cudamat* history, float l2_
                       float gradient_clip, float epsilon, float momentum);
 int sgd_momentum_step_normlimit(cudamat* grad, cudamat* param, cudamat* history, float l2_decay,
                                 float gradient_clip, float epsilon, float momentum, float norm,
-                                int constraint);   /* + ApplyConstraints (src/optimizer.cc:75-81), axis=1 */
+                                int constraint);
+/* sgd_momentum_step on `count` tensors in one launch per 16 of them (the arrays hold one entry per tensor): the many small tensors of a
+ * step — convolution banks, every bias — otherwise cost a launch each.  Element for element the same update: bit-identical to `count`
+ * calls of sgd_momentum_step. */
+int sgd_momentum_step_multi(int count, cudamat** grads, cudamat** params, cudamat** histories, const float* l2_decay,
+                            const float* gradient_clip, const float* epsilon, const float* momentum);   /* + ApplyConstraints (src/optimizer.cc:75-81), axis=1 */
 int softmax_ce_grad_correct(cudamat* logits, cudamat* labels, cudamat* probs, cudamat* deriv,
                             cudamat* correct_accum, float deriv_scale);
 int relu_dropout(rnd_struct* rnd_state, cudamat* mat, float dropprob, float scale);

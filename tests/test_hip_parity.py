@@ -493,3 +493,29 @@ def test_conv_down_mask_with_tail_split(hip, matrix_path):
         Matrix.ConvDownMask(D, W, S, T, _desc(g), st, 1.25)
         want = np.where(state > 0, (st * t0 + ref) * 1.25, 0.0).astype(np.float32)
         assert rel_err(T.ToNumpy().reshape(g.in_shape()), want) < TOL
+
+
+def test_sgd_multi_equals_one_call_per_tensor(hip):
+    """sgd_momentum_step_multi (round 6): several tensors, each with its own hyper-parameters, in one launch per 16 — bit for bit what
+    one sgd_momentum_step per tensor gives (and that entry is pinned to the reference's golden vectors above): 19 tensors (two launches),
+    sizes from 1 to 1.3 M elements, unaligned ones, l2 / clip on and off."""
+    from convnet_amd.matrix import Matrix
+    from hip_adapter import _mat
+    rng = np.random.default_rng(23)
+    sizes = [(96, 147), (1, 96), (256, 2400), (1, 256), (384, 2304), (1, 384), (384, 3456), (1, 1), (256, 3456), (1, 1000), (7, 13), (3, 5),
+             (64, 64), (1, 4096), (33, 77), (128, 9), (1, 3), (1024, 1024), (5, 1)]
+    hyper = [(0.0005 * (i % 3), 0.0 if i % 4 else 0.5, 0.01 / (1 + i % 5), 0.9 - 0.1 * (i % 2)) for i in range(len(sizes))]
+    data = [(rnd(rng, (c, r)), rnd(rng, (c, r)), rnd(rng, (c, r))) for (r, c) in sizes]
+
+    def run(multi):
+        mats = [tuple(_mat(a.copy(), r, c) for a in d) for d, (r, c) in zip(data, sizes)]
+        items = [(g, w, h, *hp) for (g, w, h), hp in zip(mats, hyper)]
+        if multi:
+            Matrix.SGDMomentumStepMulti(items)
+        else:
+            for it in items:
+                Matrix.SGDMomentumStep(*it)
+        return [tuple(m.ToNumpy() for m in t) for t in mats]
+    one, many = run(False), run(True)
+    for (g1, w1, h1), (g2, w2, h2) in zip(one, many):
+        assert np.array_equal(g1, g2) and np.array_equal(w1, w2) and np.array_equal(h1, h2)
