@@ -1983,6 +1983,10 @@ static void launch_conv_down(PendingOp& o) {
 static bool park_conv(int kind, void (*launch)(PendingOp&), cudamat* a, cudamat* b, cudamat* c, Shape4D* sa, Shape4D* sb, Shape4D* sc, const ConvDesc& d,
                       float scaleTargets) {
   if (!defer_begin(kind, launch)) return false;
+  // the call's consistency checks run NOW, so that a bad convUp / convDown fails at the call that made it and not inside whichever later
+  // call launches the parked one: kind 1 = (images, filters, targets), kind 2 = (derivs, filters, targets)
+  if (kind == 1) (void)conv_geo(sa, sb, sc, d, a, b, c);
+  else (void)conv_geo(sc, sb, sa, d, c, b, a);
   PendingOp& o = pending();
   o.m[0] = *a; o.m[1] = *b; o.m[2] = *c;
   o.s[0] = *sa; o.s[1] = *sb; o.s[2] = *sc;
