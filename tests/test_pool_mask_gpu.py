@@ -129,3 +129,48 @@ def test_maxpool_edge_uses_the_mask_only_for_its_own_forward_pass(hip):
     _lib.profile_enable(False)
     assert "pool_undo_mask_kernel<max>" not in names and any(n.startswith("pool_undo_kernel") for n in names), names
     assert np.array_equal(dxm.ToNumpy(), masked)   # the reference's call and the mask agree bit for bit
+
+
+def test_alexnet_step_with_and_without_the_masks_is_bit_identical(hip):
+    """The real AlexNet (224 x 224, 32 images, fused host path, dropout off so that both nets see the same units) trained for two steps
+    twice from the same parameters and batch: with the mask pair on its three pooling edges, and with those edges on the reference's
+    MaxPool / MaxPoolUndo(Relu) calls.  Every parameter, every gradient and every optimizer history must agree bit for bit — and so must the
+    batched plain SGD step against one call per tensor (the second net also takes its optimizer steps one by one)."""
+    from convnet_amd import _lib, models
+    from convnet_amd.edge import MaxPoolEdge
+    from test_net_gpu import build, copy_params
+    text = models.alexnet(dropprob=0.0)
+    a = build(text, 32, True, seed_data=9)
+    b = build(text, 32, True, seed_data=9)
+    copy_params(a, b)
+    for e in b.edges_:
+        if isinstance(e, MaxPoolEdge):
+            e.fused = False            # the reference's call pair
+    b_update = b.UpdateWeights
+
+    def one_by_one():                  # ... and one optimizer call per tensor
+        keep, b.fused = b.fused, False
+        try:
+            b_update()
+        finally:
+            b.fused = keep
+    b.UpdateWeights = one_by_one
+    _lib.profile_enable(True)
+    for _ in range(2):
+        a.TrainOneBatch()
+    names_a = {r["kernel"] for r in _lib.profile_report()}
+    _lib.profile_enable(False)
+    _lib.profile_enable(True)
+    for _ in range(2):
+        b.TrainOneBatch()
+    names_b = {r["kernel"] for r in _lib.profile_report()}
+    _lib.profile_enable(False)
+    assert "pool_undo_mask_kernel<max>" in names_a and "sgd_multi_kernel" in names_a, names_a
+    assert "pool_undo_mask_kernel<max>" not in names_b and "sgd_multi_kernel" not in names_b and "sgd_kernel" in names_b, names_b
+    assert np.array_equal(a.parameters_.ToNumpy(), b.parameters_.ToNumpy())
+    for ea, eb in zip(a.edges_, b.edges_):
+        if hasattr(ea, "grad_weights_"):
+            assert np.array_equal(ea.GetGradWeight().ToNumpy(), eb.GetGradWeight().ToNumpy()), ea.GetName()
+            assert np.array_equal(ea.weight_optimizer_.gradient_history_.ToNumpy(), eb.weight_optimizer_.gradient_history_.ToNumpy()), ea.GetName()
+            if not ea.has_no_bias_:
+                assert np.array_equal(ea.GetGradBias().ToNumpy(), eb.GetGradBias().ToNumpy()), ea.GetName()
